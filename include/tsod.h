@@ -1,0 +1,212 @@
+/*
+ * tsod.h -- C ABI of libtsod.so: the MI355X (gfx950) two-stage-detector forward path.
+ *
+ * Drop-in boundary.  The reference (3SAILab/two_stage_object_detection) is pure Python and has
+ * no FFI of its own: its hot path bottoms out in torch / torchvision operators.  Each entry
+ * point below replaces the operator(s) named in its comment (file:line in the reference), and
+ * is what the reference's Python modules bind through ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions (all entry points)
+ *   - plain C, no exceptions; return 0 (TSOD_OK) or a negative tsod_status.
+ *   - pointers are RAW DEVICE pointers (hipMalloc / torch tensor.data_ptr()), f32 unless said;
+ *     activation and weight pointers must be 16-byte aligned.
+ *   - asynchronous and stream-ordered on `stream` (a hipStream_t passed as void*; NULL = default).
+ *   - stateless, re-entrant, no device allocation, no host synchronisation: the caller owns
+ *     every buffer including workspaces (sizes from the *_workspace_bytes helpers), so every
+ *     call is legal inside hipStreamBeginCapture / a torch.cuda.graph.
+ *   - activations are NHWC ("pixel-major") f32: element (n,h,w,c) of a tensor with channel
+ *     pitch P and channel offset O lives at ((n*H + h)*W + w)*P + O + c.  Pitch/offset let a
+ *     conv read or write a channel slice of a wider buffer (HarDNet's concat is free).
+ *   - boxes are xyxy pixel coordinates, f32.
+ */
+#ifndef TSOD_H
+#define TSOD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSOD_VERSION 100 /* 0.1.0 */
+
+typedef void *tsod_stream_t; /* hipStream_t */
+
+typedef enum tsod_status {
+    TSOD_OK = 0,
+    TSOD_ERR_INVALID_ARG = -1, /* NULL pointer, non-positive size, inconsistent geometry */
+    TSOD_ERR_UNSUPPORTED = -2, /* valid request this build has no kernel for */
+    TSOD_ERR_ALIGNMENT = -3,   /* pointer / pitch / offset not aligned as documented */
+    TSOD_ERR_WORKSPACE = -4,   /* workspace NULL or too small */
+    TSOD_ERR_LAUNCH = -5       /* hipLaunchKernel reported an error */
+} tsod_status;
+
+const char *tsod_status_str(int status);
+int tsod_version(void);
+/* Number of compute units of the current device (used by the tile heuristics); <0 on error. */
+int tsod_device_cu_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense convolution / linear as implicit GEMM on v_mfma_f32_32x32x2_f32 (f32 in, f32 acc).
+ * Replaces nn.Conv2d(groups=1) + eval nn.BatchNorm2d + nn.PReLU/ReLU6/ReLU [+ residual add]:
+ *   models/resnet.py:62-74 (Bottleneck), :21-31 (BasicBlock), :136-138 (stem), :114-116 (downsample)
+ *   models/hardnet.py:38-55 (ConvLayer)
+ *   nets/rpn.py:86-88,107,111 (loc / score 1x1 convs)      nets/classify.py:13,15,48,50 (nn.Linear)
+ *
+ *   out[m, n] = act( (sum_k A[m,k] * Wp[n,k]) * scale[n] + shift[n] + residual[m,n] )
+ *   m = (img, oh, ow);  k = (kh, kw, ci) over the input SEGMENTS (see below);  n = output channel.
+ * ---------------------------------------------------------------------------------------- */
+enum { TSOD_ACT_NONE = 0, TSOD_ACT_PRELU = 1, TSOD_ACT_RELU6 = 2, TSOD_ACT_RELU = 3 };
+enum { TSOD_TILE_AUTO = 0, TSOD_TILE_128x128 = 1, TSOD_TILE_128x64 = 2, TSOD_TILE_64x64 = 3, TSOD_TILE_64x128 = 4,
+       TSOD_TILE_COUNT = 5 };
+#define TSOD_MAX_SEGMENTS 8
+
+typedef struct tsod_conv2d_desc {
+    int32_t N, H, W;       /* input images, height, width */
+    int32_t in_pitch;      /* floats between consecutive input pixels; multiple of 4 */
+    int32_t n_seg;         /* 1..TSOD_MAX_SEGMENTS channel segments gathered from each input pixel */
+    int32_t seg_off[TSOD_MAX_SEGMENTS]; /* first channel of segment s inside the pixel; multiple of 4 */
+    int32_t seg_len[TSOD_MAX_SEGMENTS]; /* channels in segment s; multiple of 4.  Cin = sum(seg_len) */
+    int32_t Cout;          /* output channels (any positive value) */
+    int32_t out_pitch;     /* floats between consecutive output pixels (>= out_off + Cout) */
+    int32_t out_off;       /* first output channel inside the output pixel */
+    int32_t KH, KW;        /* filter size */
+    int32_t stride;        /* same in h and w */
+    int32_t pad_h, pad_w;  /* zero padding (top/left; bottom/right implied by OH/OW) */
+    int32_t OH, OW;        /* output height / width */
+    int32_t act;           /* TSOD_ACT_* */
+    float slope;           /* PReLU negative slope (single-parameter nn.PReLU) */
+    int32_t res_pitch;     /* residual pixel pitch (ignored when residual == NULL) */
+    int32_t res_off;       /* residual channel offset */
+    int32_t tile;          /* TSOD_TILE_*; AUTO = built-in heuristic */
+    int32_t split_k;       /* >=1 explicit K split; 0 = heuristic */
+} tsod_conv2d_desc;
+
+/* Packed weight layout Wp: [Cout][KH][KW][Cin] f32 (k = (kh*KW + kw)*Cin + ci, ci running over
+ * the concatenated segments).  tsod_pack_conv_weight_f32 converts torch's [Cout][Cin_src][KH][KW]:
+ * Cin >= Cin_src, extra input channels get zero weights (used to pad 3 -> 4 channels in the
+ * stems); KW >= KW_src, extra taps on the right get zero weights (the 7x7 stem runs as 7x8). */
+int tsod_pack_conv_weight_f32(const float *w_oihw, int32_t Cout, int32_t Cin_src, int32_t KH, int32_t KW_src,
+                              int32_t Cin, int32_t KW, float *w_packed, tsod_stream_t stream);
+
+/* Bytes of workspace tsod_conv2d_f32 needs for this descriptor (0 unless K is split). */
+size_t tsod_conv2d_workspace_bytes(const tsod_conv2d_desc *d);
+/* Resolve TSOD_TILE_AUTO / split_k == 0 to the concrete choice the heuristic makes. */
+int tsod_conv2d_resolve(const tsod_conv2d_desc *d, int32_t *tile, int32_t *split_k);
+
+int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const float *w_packed,
+                    const float *scale /* [Cout] or NULL (=1) */, const float *shift /* [Cout] or NULL (=0) */,
+                    const float *residual /* or NULL */, float *out,
+                    void *workspace, size_t workspace_bytes, tsod_stream_t stream);
+
+/* nn.Linear (nets/classify.py:13,15): out[M,N] = in[M,K] @ w[N,K]^T + bias.  K % 4 == 0. */
+int tsod_linear_f32(const float *in, int32_t M, int32_t K, int32_t in_pitch, const float *w /* [N][K] */,
+                    const float *bias /* [N] or NULL */, int32_t N, float *out, int32_t out_pitch,
+                    void *workspace, size_t workspace_bytes, tsod_stream_t stream);
+size_t tsod_linear_workspace_bytes(int32_t M, int32_t K, int32_t N);
+
+/* ------------------------------------------------------------------------------------------
+ * HBM-bound layer kernels (NHWC).
+ * ---------------------------------------------------------------------------------------- */
+/* nn.MaxPool2d(3, 2, 1): models/resnet.py:98,139.  C % 4 == 0; OH = (H-1)/2+1, OW = (W-1)/2+1. */
+int tsod_maxpool3x3s2_f32(const float *in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_pitch,
+                          float *out, int32_t out_pitch, tsod_stream_t stream);
+
+/* Depthwise 3x3, pad 1, stride 1|2, + per-channel scale/shift (folded BN or bias) + optional ReLU:
+ * models/hardnet.py:21-36 (DWConvLayer) and :193-195 (tail).  w is [3][3][C]; C % 4 == 0. */
+int tsod_dwconv3x3_f32(const float *in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_pitch, int32_t in_off,
+                       const float *w, const float *scale, const float *shift, int32_t stride, int32_t relu,
+                       float *out, int32_t out_pitch, int32_t out_off, tsod_stream_t stream);
+
+/* nn.Conv2d(2G, G, 1, groups=G) + bias: models/hardnet.py:196.
+ * out[.., g] = w[g][0]*in[.., 2g] + w[g][1]*in[.., 2g+1] + bias[g].  w is [G][2]. */
+int tsod_gconv1x1_pair_f32(const float *in, int64_t pixels, int32_t G, int32_t in_pitch, const float *w,
+                           const float *bias, float *out, int32_t out_pitch, tsod_stream_t stream);
+
+/* Layout changes at the module boundary (the reference's tensors are NCHW).
+ * nchw_to_nhwc writes channels [0,C) of each pixel and zero-fills [C, C_pad) (C_pad <= out_pitch). */
+int tsod_nchw_to_nhwc_f32(const float *in, int32_t N, int32_t C, int32_t H, int32_t W,
+                          float *out, int32_t out_pitch, int32_t C_pad, tsod_stream_t stream);
+int tsod_nhwc_to_nchw_f32(const float *in, int32_t N, int32_t C, int32_t H, int32_t W, int32_t in_pitch,
+                          int32_t in_off, float *out, tsod_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RPN proposal path.
+ * ---------------------------------------------------------------------------------------- */
+/* Fused anchor shift + fg softmax + box decode + clamp + min-size test.  Replaces
+ *   utils/basic_anchors.py:27-57 (enumerate_shifted_anchor), nets/rpn.py:115-118 (softmax, fg),
+ *   utils/loc_bbox_iou.py:29-61 (loc2bbox), nets/rpn.py:45-54 (clamp, min-size keep).
+ * Anchor index a' = (y*Wf + x)*A + a.  locs holds 4 floats per anchor at
+ * locs[(img*Hf*Wf + y*Wf + x)*loc_pitch + 4a ..], scores 2 logits (bg, fg) at
+ * scores[(...)*score_pitch + 2a ..].  x is clamped to [0, clamp_x], y to [0, clamp_y]
+ * (the caller passes img_size[1], img_size[2]: reference quirk Q1 lives in the caller).
+ * Outputs: boxes [B][Hf*Wf*A][4]; fg [B][Hf*Wf*A] (softmax probability);
+ *          keys [B][Hf*Wf*A] = fg where both sides >= min_size, else -inf;
+ *          anchors_out (optional, may be NULL) [Hf*Wf*A][4] the shifted anchors. */
+int tsod_rpn_decode_f32(const float *locs, int32_t loc_pitch, const float *scores, int32_t score_pitch,
+                        const float *anchor_base /* [A][4] */, int32_t A, int32_t B, int32_t Hf, int32_t Wf,
+                        int32_t feat_stride, float clamp_x, float clamp_y, float min_size,
+                        float *boxes, float *fg, float *keys, float *anchors_out, tsod_stream_t stream);
+
+/* Per-image stable descending top-k.  Replaces torch.argsort(score, descending=True)[:n_pre] and
+ * the gathers at nets/rpn.py:56-61.  keys [B][n]; entries equal to -inf are "filtered out" and
+ * never selected; ties keep lower index first.  Outputs, per image b:
+ *   counts[b]      = n_sel = min(n_pre, #keys > -inf)                       (int32)
+ *   idx[b][k]      = source index of the k-th best, k < n_sel; -1 beyond    (int32, [B][n_pre])
+ *   boxes_out[b][k]= boxes[b][idx] (zeros beyond n_sel)                     ([B][n_pre][4]) (may be NULL)
+ *   keys_out[b][k] = keys[b][idx]  (-inf beyond n_sel)                      ([B][n_pre])    (may be NULL)
+ * n_pre <= 16384.  One workgroup per image, LDS radix-select + bitonic sort. */
+int tsod_sort_topk_desc_f32(const float *keys, const float *boxes, int32_t B, int32_t n, int32_t n_pre,
+                            int32_t *counts, int32_t *idx, float *boxes_out, float *keys_out,
+                            tsod_stream_t stream);
+
+/* Batched greedy NMS on boxes already sorted by descending score + the pad/truncate tail.
+ * Replaces torchvision.ops.nms (nets/rpn.py:63) and nets/rpn.py:65-69.
+ *   boxes [B][n_max][4], counts[b] <= n_max valid rows per image.
+ *   suppress j when IoU(i,j) > thr (strict), IoU = inter / (area_i + area_j - inter).
+ *   keep_idx [B][n_post] int32: kept indices in order, then 0,1,2,... padding (quirk Q4).
+ *   rois     [B][n_post][4]   : boxes[b][keep_idx]
+ *   n_kept   [B] int32        : min(number surviving NMS, n_post) before padding
+ *   status   [1] int32 (zeroed by the caller): bit 0 set when the pad ran past counts[b]
+ *            (the reference raises IndexError there); the offending rows are zero-filled.
+ * workspace: tsod_nms_workspace_bytes(B, n_max). */
+size_t tsod_nms_workspace_bytes(int32_t B, int32_t n_max);
+int tsod_nms_f32(const float *boxes, const int32_t *counts, int32_t B, int32_t n_max, float iou_thr,
+                 int32_t n_post, int32_t *keep_idx, float *rois, int32_t *n_kept, int32_t *status,
+                 void *workspace, size_t workspace_bytes, tsod_stream_t stream);
+
+/* Dense pairwise IoU with eps in the denominator: utils/loc_bbox_iou.py:4-27.  out [Na][Nb]. */
+int tsod_bbox_iou_f32(const float *a, int32_t Na, const float *b, int32_t Nb, float eps, float *out,
+                      tsod_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RoI head.
+ * ---------------------------------------------------------------------------------------- */
+/* torchvision.ops.RoIPool((PH,PW), spatial_scale) (nets/classify.py:17,43) on an NHWC feature map.
+ *   feat [B][Hf][Wf] pixels with pitch feat_pitch, C channels (C % 4 == 0);
+ *   rois5 [K][5] = (batch_index, x1, y1, x2, y2) in feature coordinates before spatial_scale.
+ *   out  [K][C][PH][PW]  (torchvision's layout). */
+int tsod_roi_pool_f32(const float *feat, int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t feat_pitch,
+                      const float *rois5, int32_t K, float spatial_scale, int32_t PH, int32_t PW,
+                      float *out, tsod_stream_t stream);
+
+/* Fused RoI rescale + index + RoIPool + mean over the PHxPW bins.  Replaces
+ *   nets/classify.py:29-38 (rescale: x / img_w * Wf, y / img_h * Hf; row index = roi_indices[b]),
+ *   nets/classify.py:43 (RoIPool), models/hardnet.py:203-212 (AdaptiveAvgPool2d(1) + Flatten).
+ *   rois [B][R][4] image coordinates; roi_indices [B] int32; out [B*R][C] (pitch out_pitch). */
+int tsod_roi_pool_avg_f32(const float *feat, int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t feat_pitch,
+                          const float *rois, const int32_t *roi_indices, int32_t R, float img_h, float img_w,
+                          float spatial_scale, int32_t PH, int32_t PW, float *out, int32_t out_pitch,
+                          tsod_stream_t stream);
+
+/* Final detection records (nets/frcnn_training.py:311-319): per RoI the arg-max class
+ * over all n_class logits (first max wins), its raw logit, and loc2bbox(roi, loc of that class).
+ *   cls_locs [K][4*n_class], scores [K][n_class], rois [K][4] -> det [K][6] = (x1,y1,x2,y2,score,class). */
+int tsod_detections_f32(const float *cls_locs, const float *scores, const float *rois, int32_t K,
+                        int32_t n_class, float *det, tsod_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSOD_H */

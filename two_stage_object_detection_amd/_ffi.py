@@ -1,0 +1,129 @@
+"""ctypes binding of include/tsod.h (libtsod.so, HIP, gfx950).
+
+This is the only way the package reaches compute: there is no CPU or PyTorch-eager fallback.
+If the shared library is missing the import of any compute entry point raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libtsod.so")
+
+TSOD_MAX_SEGMENTS = 8
+ACT_NONE, ACT_PRELU, ACT_RELU6, ACT_RELU = 0, 1, 2, 3
+TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4
+TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "64x128"}
+
+
+class TsodError(RuntimeError):
+    pass
+
+
+class ConvDesc(Structure):
+    """Mirror of ``tsod_conv2d_desc`` (include/tsod.h)."""
+    _fields_ = [
+        ("N", c_int32), ("H", c_int32), ("W", c_int32),
+        ("in_pitch", c_int32), ("n_seg", c_int32),
+        ("seg_off", c_int32 * TSOD_MAX_SEGMENTS), ("seg_len", c_int32 * TSOD_MAX_SEGMENTS),
+        ("Cout", c_int32), ("out_pitch", c_int32), ("out_off", c_int32),
+        ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad_h", c_int32), ("pad_w", c_int32),
+        ("OH", c_int32), ("OW", c_int32), ("act", c_int32), ("slope", c_float),
+        ("res_pitch", c_int32), ("res_off", c_int32), ("tile", c_int32), ("split_k", c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/tsod.h declares
+_SIGNATURES = {
+    "tsod_status_str": (c_char_p, [c_int]),
+    "tsod_version": (c_int, []),
+    "tsod_device_cu_count": (c_int, []),
+    "tsod_pack_conv_weight_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "tsod_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "tsod_conv2d_resolve": (c_int, [POINTER(ConvDesc), POINTER(c_int32), POINTER(c_int32)]),
+    "tsod_conv2d_f32": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_size_t, c_void_p]),
+    "tsod_linear_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32,
+                                c_void_p, c_size_t, c_void_p]),
+    "tsod_linear_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "tsod_maxpool3x3s2_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "tsod_dwconv3x3_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                   c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
+    "tsod_gconv1x1_pair_f32": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "tsod_nchw_to_nhwc_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
+    "tsod_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "tsod_rpn_decode_f32": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                    c_int32, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tsod_sort_topk_desc_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
+    "tsod_nms_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "tsod_nms_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tsod_bbox_iou_f32": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_float, c_void_p, c_void_p]),
+    "tsod_roi_pool_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_float,
+                                  c_int32, c_int32, c_void_p, c_void_p]),
+    "tsod_roi_pool_avg_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                      c_float, c_float, c_float, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "tsod_detections_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded libtsod.so.  Raises (no fallback) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TsodError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C two_stage_object_detection_amd/csrc`). There is no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise TsodError(f"{what or 'tsod call'} failed: {lib().tsod_status_str(rc).decode()} ({rc})")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int:
+    """Raw device pointer of a tensor (or 0 for None)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def require_cuda(t: torch.Tensor, what: str) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TsodError(f"{what}: this package is a HIP-only path and needs a CUDA/ROCm tensor "
+                        "(the CPU restatement lives under oracle/ and is test infrastructure only)")
+    if t.dtype != torch.float32:
+        raise TsodError(f"{what}: float32 required, got {t.dtype}")
+
+
+def make_conv_desc(*, N, H, W, in_pitch, segs, Cout, out_pitch, out_off=0, KH=1, KW=1, stride=1, pad_h=0, pad_w=0,
+                   OH=None, OW=None, act=ACT_NONE, slope=0.0, res_pitch=0, res_off=0, tile=TILE_AUTO, split_k=0) -> ConvDesc:
+    d = ConvDesc()
+    d.N, d.H, d.W, d.in_pitch = N, H, W, in_pitch
+    d.n_seg = len(segs)
+    for i, (off, ln) in enumerate(segs):
+        d.seg_off[i], d.seg_len[i] = off, ln
+    d.Cout, d.out_pitch, d.out_off = Cout, out_pitch, out_off
+    d.KH, d.KW, d.stride, d.pad_h, d.pad_w = KH, KW, stride, pad_h, pad_w
+    d.OH = OH if OH is not None else (H + 2 * pad_h - KH) // stride + 1
+    d.OW = OW if OW is not None else (W + 2 * pad_w - KW) // stride + 1
+    d.act, d.slope = act, float(slope)
+    d.res_pitch, d.res_off, d.tile, d.split_k = res_pitch, res_off, tile, split_k
+    return d

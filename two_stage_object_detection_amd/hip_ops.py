@@ -1,0 +1,252 @@
+"""Tensor-level wrappers over the C ABI (one per entry point of include/tsod.h).
+
+Every function takes CUDA/ROCm f32 tensors, allocates outputs with torch (device memory plumbing
+only) and launches the HIP kernel on torch's current stream.  No fallback of any kind.
+"""
+from __future__ import annotations
+
+import math
+from ctypes import byref, c_int32
+
+import torch
+
+from . import _ffi
+from ._ffi import ACT_NONE, check, lib, make_conv_desc, ptr, require_cuda, stream_ptr
+
+
+# ----------------------------------------------------------------------------- workspace arena
+class _Arena:
+    """One growable scratch tensor per device (split-K slabs, NMS masks)."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, device, nbytes: int) -> torch.Tensor:
+        nbytes = max(int(nbytes), 256)
+        cur = self._buf.get(device)
+        if cur is None or cur.numel() < nbytes:
+            cur = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+            self._buf[device] = cur
+        return cur
+
+
+ARENA = _Arena()
+
+
+# ----------------------------------------------------------------------------- layout
+def nchw_to_nhwc(x: torch.Tensor, c_pad: int | None = None) -> torch.Tensor:
+    """[N,C,H,W] -> [N,H,W,c_pad] (channels >= C zero-filled)."""
+    require_cuda(x, "nchw_to_nhwc")
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    c_pad = C if c_pad is None else c_pad
+    out = torch.empty((N, H, W, c_pad), dtype=torch.float32, device=x.device)
+    check(lib().tsod_nchw_to_nhwc_f32(ptr(x), N, C, H, W, ptr(out), c_pad, c_pad, stream_ptr()), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor, C: int | None = None, c_off: int = 0) -> torch.Tensor:
+    """[N,H,W,P] (channel slice [c_off, c_off+C)) -> [N,C,H,W]."""
+    require_cuda(x, "nhwc_to_nchw")
+    assert x.is_contiguous()
+    N, H, W, P = x.shape
+    C = P - c_off if C is None else C
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    check(lib().tsod_nhwc_to_nchw_f32(ptr(x), N, C, H, W, P, c_off, ptr(out), stream_ptr()), "nhwc_to_nchw")
+    return out
+
+
+# ----------------------------------------------------------------------------- conv / linear
+def pack_conv_weight(w: torch.Tensor, cin_pad: int | None = None, kw_pad: int | None = None) -> torch.Tensor:
+    """torch [Cout,Cin,KH,KW] -> packed [Cout,KH,KW_pad,Cin_pad] on the device (zero-filled padding)."""
+    require_cuda(w, "pack_conv_weight")
+    w = w.detach().contiguous()
+    Cout, Cin, KH, KW = w.shape
+    cin_pad = Cin if cin_pad is None else cin_pad
+    kw_pad = KW if kw_pad is None else kw_pad
+    out = torch.empty((Cout, KH, kw_pad, cin_pad), dtype=torch.float32, device=w.device)
+    check(lib().tsod_pack_conv_weight_f32(ptr(w), Cout, Cin, KH, KW, cin_pad, kw_pad, ptr(out), stream_ptr()),
+          "pack_conv_weight")
+    return out
+
+
+def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_logical=None, scale=None, shift=None,
+                residual=None, act=ACT_NONE, slope=0.0, segs=None, out=None, out_off=0, tile=0, split_k=0) -> torch.Tensor:
+    """Implicit-GEMM convolution on an NHWC tensor [N,H,W,P].  ``w_packed`` is [Cout,KH,KW,Cin]
+    (see pack_conv_weight); ``kw_logical`` is the filter width before zero-tap padding (it fixes OW).
+    ``segs`` = [(channel offset, length), ...] inside the P-wide pixel (default: the first Cin
+    channels).  Returns / fills an NHWC output [N,OH,OW,Pout]."""
+    require_cuda(x, "conv2d")
+    assert x.is_contiguous() and w_packed.is_contiguous()
+    N, H, W, P = x.shape
+    Cout, KH, KW, Cin = w_packed.shape
+    segs = [(0, Cin)] if segs is None else segs
+    assert sum(s[1] for s in segs) == Cin, "segments must add up to the packed Cin"
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - (KW if kw_logical is None else kw_logical)) // stride + 1
+    if out is None:
+        out = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and out.shape[:3] == (N, OH, OW)
+    d = make_conv_desc(N=N, H=H, W=W, in_pitch=P, segs=segs, Cout=Cout, out_pitch=out.shape[3], out_off=out_off,
+                       KH=KH, KW=KW, stride=stride, pad_h=pad, pad_w=pad, OH=OH, OW=OW, act=act, slope=slope,
+                       res_pitch=0 if residual is None else residual.shape[-1], res_off=0, tile=tile, split_k=split_k)
+    ws_bytes = lib().tsod_conv2d_workspace_bytes(byref(d))
+    ws = ARENA.get(x.device, ws_bytes) if ws_bytes else None
+    check(lib().tsod_conv2d_f32(byref(d), ptr(x), ptr(w_packed), ptr(scale), ptr(shift), ptr(residual), ptr(out),
+                                ptr(ws), ws_bytes, stream_ptr()), "conv2d")
+    return out
+
+
+def conv2d_resolve(d) -> tuple[int, int]:
+    t, s = c_int32(0), c_int32(0)
+    check(lib().tsod_conv2d_resolve(byref(d), byref(t), byref(s)), "conv2d_resolve")
+    return t.value, s.value
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """nn.Linear: x [M,K] @ weight[N,K]^T + bias."""
+    require_cuda(x, "linear")
+    x = x.contiguous()
+    weight = weight.detach().contiguous()
+    M, K = x.shape
+    N = weight.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    ws_bytes = lib().tsod_linear_workspace_bytes(M, K, N)
+    ws = ARENA.get(x.device, ws_bytes) if ws_bytes else None
+    check(lib().tsod_linear_f32(ptr(x), M, K, K, ptr(weight), ptr(bias), N, ptr(out), N, ptr(ws), ws_bytes,
+                                stream_ptr()), "linear")
+    return out
+
+
+# ----------------------------------------------------------------------------- HBM-bound layers
+def maxpool3x3s2_nhwc(x: torch.Tensor) -> torch.Tensor:
+    require_cuda(x, "maxpool")
+    N, H, W, C = x.shape
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
+    check(lib().tsod_maxpool3x3s2_f32(ptr(x), N, H, W, C, C, ptr(out), C, stream_ptr()), "maxpool")
+    return out
+
+
+def dwconv3x3_nhwc(x: torch.Tensor, w33c: torch.Tensor, scale=None, shift=None, stride=1, relu=False, C=None,
+                   in_off=0, out=None, out_off=0) -> torch.Tensor:
+    """Depthwise 3x3 pad 1 on channels [in_off, in_off+C) of x [N,H,W,P]; w33c is [3,3,C]."""
+    require_cuda(x, "dwconv3x3")
+    N, H, W, P = x.shape
+    C = w33c.shape[2] if C is None else C
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
+    check(lib().tsod_dwconv3x3_f32(ptr(x), N, H, W, C, P, in_off, ptr(w33c), ptr(scale), ptr(shift), stride,
+                                   1 if relu else 0, ptr(out), out.shape[3], out_off, stream_ptr()), "dwconv3x3")
+    return out
+
+
+def gconv1x1_pair_nhwc(x: torch.Tensor, w_g2: torch.Tensor, bias=None) -> torch.Tensor:
+    require_cuda(x, "gconv1x1_pair")
+    N, H, W, P = x.shape
+    G = w_g2.shape[0]
+    out = torch.empty((N, H, W, G), dtype=torch.float32, device=x.device)
+    check(lib().tsod_gconv1x1_pair_f32(ptr(x), N * H * W, G, P, ptr(w_g2), ptr(bias), ptr(out), G, stream_ptr()),
+          "gconv1x1_pair")
+    return out
+
+
+# ----------------------------------------------------------------------------- proposal path
+def rpn_decode(locs: torch.Tensor, scores: torch.Tensor, anchor_base: torch.Tensor, B, Hf, Wf, feat_stride,
+               clamp_x, clamp_y, min_size, want_anchors=False):
+    """locs [B*Hf*Wf, 4A] , scores [B*Hf*Wf, 2A] (row pitch = last dim) ->
+    boxes [B,Hf*Wf*A,4], fg [B,n], keys [B,n] (+ anchors [n,4])."""
+    require_cuda(locs, "rpn_decode")
+    A = anchor_base.shape[0]
+    n = Hf * Wf * A
+    dev = locs.device
+    boxes = torch.empty((B, n, 4), dtype=torch.float32, device=dev)
+    fg = torch.empty((B, n), dtype=torch.float32, device=dev)
+    keys = torch.empty((B, n), dtype=torch.float32, device=dev)
+    anchors = torch.empty((n, 4), dtype=torch.float32, device=dev) if want_anchors else None
+    check(lib().tsod_rpn_decode_f32(ptr(locs), locs.shape[-1], ptr(scores), scores.shape[-1], ptr(anchor_base), A, B,
+                                    Hf, Wf, feat_stride, float(clamp_x), float(clamp_y), float(min_size), ptr(boxes),
+                                    ptr(fg), ptr(keys), ptr(anchors), stream_ptr()), "rpn_decode")
+    return boxes, fg, keys, anchors
+
+
+def sort_topk_desc(keys: torch.Tensor, boxes: torch.Tensor | None, n_pre: int):
+    """keys [B,n] (-inf = filtered), boxes [B,n,4] -> counts [B] i32, idx [B,n_pre] i32,
+    boxes_sorted [B,n_pre,4], keys_sorted [B,n_pre]."""
+    require_cuda(keys, "sort_topk")
+    B, n = keys.shape
+    dev = keys.device
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    idx = torch.empty((B, n_pre), dtype=torch.int32, device=dev)
+    bs = torch.empty((B, n_pre, 4), dtype=torch.float32, device=dev) if boxes is not None else None
+    ks = torch.empty((B, n_pre), dtype=torch.float32, device=dev)
+    check(lib().tsod_sort_topk_desc_f32(ptr(keys), ptr(boxes), B, n, n_pre, ptr(counts), ptr(idx), ptr(bs), ptr(ks),
+                                        stream_ptr()), "sort_topk")
+    return counts, idx, bs, ks
+
+
+def nms_sorted(boxes_sorted: torch.Tensor, counts: torch.Tensor, iou_thr: float, n_post: int, status=None):
+    """boxes_sorted [B,n_max,4] in descending-score order, counts [B] i32 ->
+    keep_idx [B,n_post] i32, rois [B,n_post,4], n_kept [B] i32, status [1] i32."""
+    require_cuda(boxes_sorted, "nms")
+    B, n_max, _ = boxes_sorted.shape
+    dev = boxes_sorted.device
+    keep = torch.empty((B, n_post), dtype=torch.int32, device=dev)
+    rois = torch.empty((B, n_post, 4), dtype=torch.float32, device=dev)
+    n_kept = torch.empty((B,), dtype=torch.int32, device=dev)
+    if status is None:
+        status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws_bytes = lib().tsod_nms_workspace_bytes(B, n_max)
+    ws = ARENA.get(dev, ws_bytes)
+    check(lib().tsod_nms_f32(ptr(boxes_sorted), ptr(counts), B, n_max, float(iou_thr), n_post, ptr(keep), ptr(rois),
+                             ptr(n_kept), ptr(status), ptr(ws), ws_bytes, stream_ptr()), "nms")
+    return keep, rois, n_kept, status
+
+
+def bbox_iou(a: torch.Tensor, b: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    require_cuda(a, "bbox_iou")
+    if a.shape[1] != 4 or b.shape[1] != 4:
+        raise IndexError
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    if out.numel():
+        check(lib().tsod_bbox_iou_f32(ptr(a), a.shape[0], ptr(b), b.shape[0], float(eps), ptr(out), stream_ptr()),
+              "bbox_iou")
+    return out
+
+
+# ----------------------------------------------------------------------------- RoI head
+def roi_pool_nhwc(feat: torch.Tensor, rois5: torch.Tensor, output_size=(7, 7), spatial_scale=1.0) -> torch.Tensor:
+    """feat [B,Hf,Wf,C] NHWC, rois5 [K,5] -> [K,C,PH,PW] (torchvision layout)."""
+    require_cuda(feat, "roi_pool")
+    B, Hf, Wf, C = feat.shape
+    K = rois5.shape[0]
+    PH, PW = output_size
+    out = torch.empty((K, C, PH, PW), dtype=torch.float32, device=feat.device)
+    check(lib().tsod_roi_pool_f32(ptr(feat), B, Hf, Wf, C, C, ptr(rois5.contiguous()), K, float(spatial_scale), PH, PW,
+                                  ptr(out), stream_ptr()), "roi_pool")
+    return out
+
+
+def roi_pool_avg_nhwc(feat: torch.Tensor, rois: torch.Tensor, roi_indices: torch.Tensor, img_h, img_w,
+                      output_size=(7, 7), spatial_scale=1.0) -> torch.Tensor:
+    """feat [B,Hf,Wf,C], rois [B,R,4] image coords, roi_indices [B] i32 -> [B*R, C]."""
+    require_cuda(feat, "roi_pool_avg")
+    B, Hf, Wf, C = feat.shape
+    R = rois.shape[1]
+    PH, PW = output_size
+    out = torch.empty((rois.shape[0] * R, C), dtype=torch.float32, device=feat.device)
+    check(lib().tsod_roi_pool_avg_f32(ptr(feat), B, Hf, Wf, C, C, ptr(rois.contiguous()),
+                                      ptr(roi_indices.to(torch.int32).contiguous()), R, float(img_h), float(img_w),
+                                      float(spatial_scale), PH, PW, ptr(out), C, stream_ptr()), "roi_pool_avg")
+    return out
+
+
+def detections(cls_locs: torch.Tensor, scores: torch.Tensor, rois: torch.Tensor) -> torch.Tensor:
+    """[B,R,4*n_class], [B,R,n_class], [B,R,4] -> [B,R,6] (x1,y1,x2,y2,score,class)."""
+    require_cuda(scores, "detections")
+    B, R, n_class = scores.shape
+    out = torch.empty((B, R, 6), dtype=torch.float32, device=scores.device)
+    check(lib().tsod_detections_f32(ptr(cls_locs.contiguous()), ptr(scores.contiguous()), ptr(rois.contiguous()), B * R,
+                                    n_class, ptr(out), stream_ptr()), "detections")
+    return out
