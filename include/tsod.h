@@ -149,6 +149,13 @@ int tsod_rpn_decode_f32(const float *locs, int32_t loc_pitch, const float *score
                         int32_t feat_stride, float clamp_x, float clamp_y, float min_size,
                         float *boxes, float *fg, float *keys, float *anchors_out, tsod_stream_t stream);
 
+/* utils/basic_anchors.py:27-57 as a stand-alone op: out [Hf*Wf*A][4] = base[a] + (x*s, y*s, x*s, y*s). */
+int tsod_enumerate_anchors_f32(const float *anchor_base, int32_t A, int32_t Hf, int32_t Wf, int32_t feat_stride,
+                               float *out, tsod_stream_t stream);
+
+/* utils/loc_bbox_iou.py:29-61 as a stand-alone op: src [n][4] xyxy, loc [n][4] (dx,dy,dw,dh) -> out [n][4]. */
+int tsod_loc2bbox_f32(const float *src, const float *loc, int64_t n, float *out, tsod_stream_t stream);
+
 /* Per-image stable descending top-k.  Replaces torch.argsort(score, descending=True)[:n_pre] and
  * the gathers at nets/rpn.py:56-61.  keys [B][n]; entries equal to -inf are "filtered out" and
  * never selected; ties keep lower index first.  Outputs, per image b:

@@ -1,0 +1,52 @@
+"""The C-ABI library loads and exports every symbol include/tsod.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from two_stage_object_detection_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tsod.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsod_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(_ffi.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_ffi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    raw = ctypes.CDLL(_ffi.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(raw, name), name
+    lib = _ffi.lib()
+    assert lib.tsod_version() == 100
+    assert lib.tsod_status_str(0) == b"ok"
+    assert b"workspace" in lib.tsod_status_str(-4)
+
+
+def test_conv_desc_layout_matches_header():
+    # 5 + 8 + 8 + 3 + 5 + 2 + 1 + 1(float) + 4 int32-sized fields
+    assert ctypes.sizeof(_ffi.ConvDesc) == 4 * (5 + 8 + 8 + 3 + 5 + 2 + 1 + 1 + 4)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_ffi.TsodError, match="no CPU fallback"):
+        _ffi.lib()
+
+
+def test_cpu_tensors_are_refused():
+    import torch
+    from two_stage_object_detection_amd import hip_ops
+    with pytest.raises(_ffi.TsodError, match="HIP-only"):
+        hip_ops.bbox_iou(torch.zeros(2, 4), torch.zeros(2, 4))

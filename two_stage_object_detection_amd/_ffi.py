@@ -58,6 +58,8 @@ _SIGNATURES = {
     "tsod_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "tsod_rpn_decode_f32": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tsod_enumerate_anchors_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "tsod_loc2bbox_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "tsod_sort_topk_desc_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p]),
     "tsod_nms_workspace_bytes": (c_size_t, [c_int32, c_int32]),

@@ -77,6 +77,30 @@ rpn_decode_kernel(const float *__restrict__ locs, int loc_pitch, const float *__
     }
 }
 
+__global__ void __launch_bounds__(256)
+enumerate_anchors_kernel(const float *__restrict__ anchor_base, int A, int Hf, int Wf, int feat_stride,
+                         float *__restrict__ out) {
+    const long total = (long)Hf * Wf * A;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int pix = (int)(t / A);
+        const int a = (int)(t - (long)pix * A);
+        const int y = pix / Wf, x = pix - y * Wf;
+        const float sx = (float)(x * feat_stride), sy = (float)(y * feat_stride);
+        reinterpret_cast<float4 *>(out)[t] = make_float4(anchor_base[4 * a] + sx, anchor_base[4 * a + 1] + sy,
+                                                         anchor_base[4 * a + 2] + sx, anchor_base[4 * a + 3] + sy);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+loc2bbox_kernel(const float *__restrict__ src, const float *__restrict__ loc, long n, float *__restrict__ out) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const float4 s = reinterpret_cast<const float4 *>(src)[t];
+        const float4 l = reinterpret_cast<const float4 *>(loc)[t];
+        const Box o = decode_box(s.x, s.y, s.z, s.w, l.x, l.y, l.z, l.w);
+        reinterpret_cast<float4 *>(out)[t] = make_float4(o.x1, o.y1, o.x2, o.y2);
+    }
+}
+
 // One wave per RoI: arg-max over n_class logits (first maximum wins), then loc2bbox with the
 // 4 offsets of that class (nets/frcnn_training.py:311-319).
 __global__ void __launch_bounds__(256)
@@ -132,5 +156,25 @@ extern "C" int tsod_detections_f32(const float *cls_locs, const float *scores, c
     const int waves_per_block = 4;
     hipLaunchKernelGGL(detections_kernel, dim3((K + waves_per_block - 1) / waves_per_block), dim3(64 * waves_per_block),
                        0, tsod_stream(stream), cls_locs, scores, rois, K, n_class, det);
+    return tsod_launch_status();
+}
+
+extern "C" int tsod_enumerate_anchors_f32(const float *anchor_base, int32_t A, int32_t Hf, int32_t Wf,
+                                          int32_t feat_stride, float *out, tsod_stream_t stream) {
+    TSOD_REQUIRE(anchor_base && out, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(A > 0 && Hf > 0 && Wf > 0 && feat_stride > 0, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(tsod_aligned16(out), TSOD_ERR_ALIGNMENT);
+    const long total = (long)Hf * Wf * A;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(enumerate_anchors_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), anchor_base, A, Hf, Wf,
+                       feat_stride, out);
+    return tsod_launch_status();
+}
+
+extern "C" int tsod_loc2bbox_f32(const float *src, const float *loc, int64_t n, float *out, tsod_stream_t stream) {
+    TSOD_REQUIRE(src && loc && out && n > 0, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(tsod_aligned16(src) && tsod_aligned16(loc) && tsod_aligned16(out), TSOD_ERR_ALIGNMENT);
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(loc2bbox_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), src, loc, (long)n, out);
     return tsod_launch_status();
 }

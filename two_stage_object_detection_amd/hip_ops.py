@@ -170,6 +170,24 @@ def rpn_decode(locs: torch.Tensor, scores: torch.Tensor, anchor_base: torch.Tens
     return boxes, fg, keys, anchors
 
 
+def enumerate_anchors(anchor_base: torch.Tensor, feat_stride: int, height: int, width: int) -> torch.Tensor:
+    require_cuda(anchor_base, "enumerate_anchors")
+    base = anchor_base.contiguous()
+    out = torch.empty((height * width * base.shape[0], 4), dtype=torch.float32, device=base.device)
+    check(lib().tsod_enumerate_anchors_f32(ptr(base), base.shape[0], height, width, int(feat_stride), ptr(out),
+                                           stream_ptr()), "enumerate_anchors")
+    return out
+
+
+def loc2bbox(src: torch.Tensor, loc: torch.Tensor) -> torch.Tensor:
+    require_cuda(loc, "loc2bbox")
+    src, loc = src.to(loc.dtype).contiguous(), loc.contiguous()
+    out = torch.empty_like(loc)
+    if loc.shape[0]:
+        check(lib().tsod_loc2bbox_f32(ptr(src), ptr(loc), loc.shape[0], ptr(out), stream_ptr()), "loc2bbox")
+    return out
+
+
 def sort_topk_desc(keys: torch.Tensor, boxes: torch.Tensor | None, n_pre: int):
     """keys [B,n] (-inf = filtered), boxes [B,n,4] -> counts [B] i32, idx [B,n_pre] i32,
     boxes_sorted [B,n_pre,4], keys_sorted [B,n_pre]."""
