@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the full Faster R-CNN ResNet-50 inference forward on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one detector forward (NCHW->NHWC, 53 conv GEMMs, max pool, RPN convs + decode + top-k +
+NMS + pad, fused RoI pool + mean, 2 linears, detection records) over one batch of synthetic
+3x800x1333 images that is already resident in HBM, plus - for N > 1 - the RCCL all-gather of the
+[B,300,6] detection records.  Workload at N=1 = BASELINE.json configs[1] (batch 1).  Weak scaling:
+every rank processes its own batch; value = images of all ranks / max-over-ranks time.
+
+The JSON line also carries
+  roofline     : f32-MFMA roofline of the dominant kernel family (conv_igemm_kernel, all launches of one
+                 forward): algorithmic FLOPs / HIP-event time of those launches, vs 157.3 TFLOP/s.
+  cpu_baseline : the CPU oracle (torch CPU ops + C nms/roi_pool restatement of the reference's path)
+                 timed on this box's host cores on the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (configs[1] = 1, configs[2] = 16)")
+    ap.add_argument("--backbone", default="resnet50")
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--num-classes", type=int, default=80)
+    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--verbose", action="store_true")
+    return ap.parse_args()
+
+
+def conv_event_times(plan, reps=5):
+    """HIP-event duration of every conv_igemm launch of the plan (ms), on the launch stream."""
+    from two_stage_object_detection_amd._ffi import lib, stream_ptr
+    L = lib()
+    out = []
+    s = stream_ptr()
+    for st in plan.conv_steps:
+        L.tsod_conv2d_f32(*st.args, s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            L.tsod_conv2d_f32(*st.args, s)
+        e1.record()
+        e1.synchronize()
+        out.append(e0.elapsed_time(e1) / reps)
+    return out
+
+
+def cpu_baseline(sd, backbone, x_cpu, reps):
+    import oracle
+    torch.set_num_threads(os.cpu_count() or 1)
+    with torch.inference_mode():
+        oracle.detector_forward(sd, x_cpu, backbone=backbone)           # warm-up
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            oracle.detector_forward(sd, x_cpu, backbone=backbone)
+            ts.append(time.perf_counter() - t0)
+    med = statistics.median(ts)
+    return {"value": x_cpu.shape[0] / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} timed forwards (median) of the same workload: batch {x_cpu.shape[0]} x 3x{x_cpu.shape[2]}x"
+                      f"{x_cpu.shape[3]}, {backbone} detector, torch {torch.__version__} CPU f32 + oracle/box_ops.c",
+            "seconds_per_forward": med}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world != args.gpus and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    n_gpus = world if world > 1 else 1
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the package has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from two_stage_object_detection_amd import hip_ops
+    from two_stage_object_detection_amd.dist import all_gather_detections
+    from two_stage_object_detection_amd.testing import synthetic_detector
+
+    model, sd = synthetic_detector(args.backbone, num_classes=args.num_classes, seed=0)
+    model = model.to(dev).eval()
+    B = args.batch
+    x_cpu = torch.rand(B, 3, args.height, args.width, generator=torch.Generator().manual_seed(1234 + rank))
+    x = x_cpu.to(dev)
+
+    with torch.inference_mode():
+        model(x)                                                       # builds the plan
+        torch.cuda.synchronize()
+        plan = model.extractor._plan_for(x)
+        if not args.no_autotune:
+            res = plan.autotune(verbose=args.verbose and rank == 0)
+        conv_ms = conv_event_times(plan)
+        conv_flops = sum(st.flops for st in plan.conv_steps)
+        if args.no_graph:
+            def step():
+                outs = model(x)
+                return hip_ops.detections(outs[0], outs[1], outs[2])
+        else:
+            run, static_in, static_out = model.make_graphed(x)
+
+            def step():
+                return run()[4]
+        gathered = None
+        if world > 1:
+            R = step().shape[1]
+            gathered = torch.empty((world * B, R, 6), dtype=torch.float32, device=dev)
+
+        def full_step():
+            det = step()
+            if world > 1:
+                all_gather_detections(det, out=gathered)
+            return det
+
+        for _ in range(max(args.warmup, 1)):
+            full_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            full_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        model.raise_if_error()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_gpus * B * args.steps / elapsed
+        conv_total_ms = sum(conv_ms)
+        achieved = conv_flops / (conv_total_ms * 1e-3) / 1e12
+        line = {
+            "metric": "images/sec Faster R-CNN ResNet-50 @800x1333" if args.backbone == "resnet50"
+                      else f"images/sec Faster R-CNN {args.backbone} @{args.height}x{args.width}",
+            "value": round(value, 3), "unit": "images/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Full Faster R-CNN {args.backbone} inference forward, batch={B} per GPU, "
+                                   f"3x{args.height}x{args.width}, {args.num_classes}+1 classes, 3000->300 proposals",
+                       "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}",
+                       "hip_graph": not args.no_graph, "autotuned_tiles": not args.no_autotune},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": f"conv_igemm_kernel (f32 MFMA implicit GEMM), {len(conv_ms)} launches per forward",
+                         "flops_per_forward": conv_flops, "kernel_ms_per_forward": round(conv_total_ms, 4),
+                         "share_of_step": round(conv_total_ms / ms_per_step, 4)},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, args.backbone, x_cpu, args.cpu_reps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

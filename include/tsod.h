@@ -60,7 +60,7 @@ int tsod_device_cu_count(void);
 enum { TSOD_ACT_NONE = 0, TSOD_ACT_PRELU = 1, TSOD_ACT_RELU6 = 2, TSOD_ACT_RELU = 3 };
 enum { TSOD_TILE_AUTO = 0, TSOD_TILE_128x128 = 1, TSOD_TILE_128x64 = 2, TSOD_TILE_64x64 = 3, TSOD_TILE_64x128 = 4,
        TSOD_TILE_COUNT = 5 };
-#define TSOD_MAX_SEGMENTS 8
+#define TSOD_MAX_SEGMENTS 16
 
 typedef struct tsod_conv2d_desc {
     int32_t N, H, W;       /* input images, height, width */
@@ -148,6 +148,12 @@ int tsod_rpn_decode_f32(const float *locs, int32_t loc_pitch, const float *score
                         const float *anchor_base /* [A][4] */, int32_t A, int32_t B, int32_t Hf, int32_t Wf,
                         int32_t feat_stride, float clamp_x, float clamp_y, float min_size,
                         float *boxes, float *fg, float *keys, float *anchors_out, tsod_stream_t stream);
+
+/* The same decode for an explicit anchor tensor and ready-made fg scores: the head of
+ * ProposalCreator.__call__ (nets/rpn.py:44-54) for one image.  anchor [n][4], loc [n][4], score [n] ->
+ * boxes [n][4] (decoded, clamped), keys [n] = score where both sides >= min_size else -inf. */
+int tsod_proposal_decode_f32(const float *anchor, const float *loc, const float *score, int64_t n, float clamp_x,
+                             float clamp_y, float min_size, float *boxes, float *keys, tsod_stream_t stream);
 
 /* utils/basic_anchors.py:27-57 as a stand-alone op: out [Hf*Wf*A][4] = base[a] + (x*s, y*s, x*s, y*s). */
 int tsod_enumerate_anchors_f32(const float *anchor_base, int32_t A, int32_t Hf, int32_t Wf, int32_t feat_stride,

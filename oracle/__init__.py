@@ -18,5 +18,5 @@ from .box import (  # noqa: F401
     generate_basic_anchor, enumerate_shifted_anchor, loc2bbox, bbox_iou,
     nms, roi_pool, proposal_layer, rpn_forward, roi_head_forward,
 )
-from .backbones import resnet_trunk, hardnet_trunk  # noqa: F401
+from .backbones import resnet_trunk, hardnet_trunk, calibrate_bn  # noqa: F401
 from .detector import detector_forward, detections_from_outputs  # noqa: F401

@@ -19,7 +19,13 @@ import torch.nn.functional as F
 _BN_EPS = 1e-5  # nn.BatchNorm2d default, used everywhere in models/*.py
 
 
+_CALIBRATE = {"on": False}
+
+
 def _bn(sd, p, x):
+    if _CALIBRATE["on"]:   # test-data generation only: give BN the statistics a trained net would hold
+        sd[p + ".running_mean"] = x.mean(dim=(0, 2, 3))
+        sd[p + ".running_var"] = x.var(dim=(0, 2, 3), unbiased=False).clamp_min(1e-6)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
                         sd[p + ".weight"], sd[p + ".bias"], False, 0.0, _BN_EPS)
 
@@ -60,6 +66,8 @@ def resnet_trunk(sd, x, prefix="", upto=4, return_stages=False):
             x = _res_block(g, f"layer{li}.{bi}", x, stride)
             bi += 1
         stages.append(x)
+    if _CALIBRATE["on"]:
+        sd.update({prefix + k: v for k, v in g.items()})
     return (x, stages) if return_stages else x
 
 
@@ -129,4 +137,21 @@ def hardnet_trunk(sd, x, arch=39, prefix=""):
     x = F.relu(x); n += 1
     x = F.conv2d(x, g[f"base.{n}.weight"], g[f"base.{n}.bias"], 2, 1, 1, c); n += 1
     x = F.conv2d(x, g[f"base.{n}.weight"], g[f"base.{n}.bias"], 1, 0, 1, 512)
+    if _CALIBRATE["on"]:
+        sd.update({prefix + k: v for k, v in g.items()})
     return x
+
+
+def calibrate_bn(sd, x, trunk, **kw):
+    """Overwrite every BatchNorm's running statistics in ``sd`` with the batch statistics of ``x``
+    flowing through ``trunk`` (resnet_trunk / hardnet_trunk).  Synthetic-weight conditioning for
+    tests: a random-init HarDNet with identity BN squashes the image signal to a spatially constant
+    feature map, which makes ~all RPN scores tie exactly - a case in which the reference's own
+    (unstable) argsort has no defined order."""
+    _CALIBRATE["on"] = True
+    try:
+        with torch.no_grad():
+            trunk(sd, x, **kw)
+    finally:
+        _CALIBRATE["on"] = False
+    return sd

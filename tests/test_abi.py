@@ -34,8 +34,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_conv_desc_layout_matches_header():
-    # 5 + 8 + 8 + 3 + 5 + 2 + 1 + 1(float) + 4 int32-sized fields
-    assert ctypes.sizeof(_ffi.ConvDesc) == 4 * (5 + 8 + 8 + 3 + 5 + 2 + 1 + 1 + 4)
+    # 5 + 16 + 16 + 3 + 5 + 2 + 1 + 1(float) + 4 int32-sized fields
+    assert ctypes.sizeof(_ffi.ConvDesc) == 4 * (5 + 16 + 16 + 3 + 5 + 2 + 1 + 1 + 4)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -1,0 +1,62 @@
+"""The N>1 path on CPU: world_size-2 gloo run of the sharding + detection all-gather used by bench.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from two_stage_object_detection_amd.dist import all_gather_detections, global_roi_indices, shard_range
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        global_batch, R = 6, 300
+        lo, hi = shard_range(global_batch, rank, world)
+        # the "detections" of image g are filled with g so the gathered order is checkable
+        det_local = torch.stack([torch.full((R, 6), float(g)) for g in range(lo, hi)])
+        out = all_gather_detections(det_local)
+        ok = out.shape == (global_batch, R, 6) and all(bool((out[g] == g).all()) for g in range(global_batch))
+        idx = global_roi_indices(torch.arange(hi - lo, dtype=torch.int32), rank, hi - lo)
+        ok = ok and idx.tolist() == list(range(lo, hi))
+        # pre-allocated output buffer variant (what bench.py uses)
+        buf = torch.empty(global_batch, R, 6)
+        ok = ok and torch.equal(all_gather_detections(det_local, out=buf), out)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgather_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_shard_range():
+    assert [shard_range(64, r, 8) for r in (0, 7)] == [(0, 8), (56, 64)]
+    with pytest.raises(ValueError):
+        shard_range(10, 0, 4)
+
+
+def test_single_process_is_identity():
+    d = torch.randn(2, 300, 6)
+    assert all_gather_detections(d) is d

@@ -1,0 +1,208 @@
+"""GPU parity of the module surface (models/*, nets/*) against the CPU oracle.
+
+Stage-wise tests feed each HIP stage the ORACLE's input, so a discrete decision that flips under
+f32 noise (sort tie, IoU threshold, RoI rounding) cannot cascade; the end-to-end tests then compare
+the whole detector and report margins.  Tolerance (north star): boxes / scores 1e-3 absolute, class
+indices exact.  Backbone features are compared relative to their abs-max (random-init ResNet
+activations reach ~100): 2e-5 * absmax, i.e. the f32 noise floor of two different
+summation orders, ~10x tighter than what 1e-3 on the final outputs needs."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle.detector import extractor_forward
+
+pytestmark = pytest.mark.gpu
+
+
+def _img(shape, seed=1234):
+    return torch.rand(shape, generator=torch.Generator().manual_seed(seed))
+
+
+def _feat_close(got_nchw, ref, rel=2e-5):
+    scale = float(ref.abs().max())
+    err = float((got_nchw - ref).abs().max())
+    assert err <= rel * scale + 1e-6, (err, scale)
+    return err / scale
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from two_stage_object_detection_amd.testing import synthetic_detector
+    cache = {}
+
+    def get(backbone, num_classes=20, mode="training"):
+        key = (backbone, num_classes, mode)
+        if key not in cache:
+            model, sd = synthetic_detector(backbone, num_classes=num_classes, seed=0, mode=mode)
+            if backbone.startswith("hardnet"):
+                # random-init HarDNet with identity BN maps every image to a spatially constant feature map
+                # (~all 3000 RPN scores tie exactly; the reference's argsort is undefined there): give BN the
+                # batch statistics a trained net would hold.  Test-data conditioning only.
+                oracle.calibrate_bn(sd, _img((2, 3, 256, 320), seed=99), oracle.hardnet_trunk, arch=int(backbone[-2:]),
+                                    prefix="extractor.")
+                model.load_state_dict(sd)
+            cache[key] = (model.to("cuda:0").eval(), sd)
+        return cache[key]
+    return get
+
+
+# ----------------------------------------------------------------------------- backbones
+@pytest.mark.parametrize("shape", [(2, 3, 160, 224), (1, 3, 600, 600), (1, 3, 800, 1333)])
+def test_resnet50_trunk(dev, shape):
+    """BASELINE config 1 geometry (3x600x600 -> [1,2048,19,19]) and the headline 800x1333."""
+    from two_stage_object_detection_amd.models.resnet import resnet50
+    torch.manual_seed(0)
+    m = resnet50(include_top=False).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = _img(shape)
+    with torch.inference_mode():
+        ref = oracle.resnet_trunk(sd, x)
+        got = m.to(dev)(x.to(dev)).cpu()
+    assert got.shape == ref.shape
+    if shape[2:] == (600, 600):
+        assert tuple(got.shape) == (1, 2048, 19, 19)
+    if shape[2:] == (800, 1333):
+        assert tuple(got.shape) == (1, 2048, 25, 42)
+    _feat_close(got, ref)
+
+
+def test_resnet34_basicblock_trunk(dev):
+    from two_stage_object_detection_amd.models.resnet import resnet34
+    torch.manual_seed(1)
+    m = resnet34(include_top=False).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = _img((1, 3, 128, 160))
+    with torch.inference_mode():
+        _feat_close(m.to(dev)(x.to(dev)).cpu(), oracle.resnet_trunk(sd, x))
+
+
+def test_resnet_bn_fold_and_prelu_are_honoured(dev):
+    """Non-trivial BN statistics and PReLU slopes (the seeded init has identity BN)."""
+    from two_stage_object_detection_amd.models.resnet import ResNet, Bottleneck
+    torch.manual_seed(2)
+    m = ResNet(Bottleneck, [1, 1, 1, 1], include_top=False).eval()
+    g = torch.Generator().manual_seed(3)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+            mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
+            mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+        if isinstance(mod, torch.nn.PReLU):
+            mod.weight.data.fill_(float(torch.rand(1, generator=g)) * 0.4)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = _img((2, 3, 96, 128))
+    with torch.inference_mode():
+        _feat_close(m.to(dev)(x.to(dev)).cpu(), oracle.resnet_trunk(sd, x))
+
+
+@pytest.mark.parametrize("arch,shape", [(39, (2, 3, 96, 128)), (68, (1, 3, 128, 160)), (85, (1, 3, 64, 96)),
+                                        (39, (1, 3, 600, 600))])
+def test_hardnet_trunk(dev, arch, shape):
+    from two_stage_object_detection_amd.models.hardnet import HarDNetFeatureExtraction
+    torch.manual_seed(0)
+    m = HarDNetFeatureExtraction(depth_wise=True, arch=arch).eval()
+    g = torch.Generator().manual_seed(4)
+    for mod in m.modules():                                   # exercise the BN fold
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.05)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = _img(shape)
+    with torch.inference_mode():
+        ref = oracle.hardnet_trunk(sd, x, arch=arch)
+        got = m.to(dev)(x.to(dev)).cpu()
+    assert got.shape == ref.shape
+    if shape[2:] == (600, 600):
+        assert tuple(got.shape) == (1, 512, 38, 38)          # reference __main__ shape check (models/hardnet.py:214-222)
+    _feat_close(got, ref, rel=5e-5)
+
+
+# ----------------------------------------------------------------------------- stage-wise detector
+@pytest.mark.parametrize("backbone,shape", [("resnet50", (2, 3, 320, 448)), ("hardnet39", (2, 3, 320, 448))])
+def test_rpn_and_head_stagewise(dev, synth, backbone, shape):
+    model, sd = synth(backbone)
+    x = _img(shape)
+    with torch.inference_mode():
+        ref_out, dbg = oracle.detector_forward(sd, x, backbone=backbone, return_debug=True)
+        feat = dbg["feat"]
+        # RPN fed the oracle's feature map (module-level NCHW entry point)
+        locs, scores, rois, anchor = model.rpn(feat.to(dev), tuple(x.shape[1:]), 1.0)
+        model.rpn.raise_if_error()
+        assert torch.equal(anchor.cpu(), dbg["anchor"])
+        assert (locs.cpu() - dbg["rpn_locs"]).abs().max().item() < 1e-3
+        assert (scores.cpu() - dbg["rpn_scores"]).abs().max().item() < 1e-3
+        d = (rois.cpu().unsqueeze(2) - ref_out[2].unsqueeze(1)).abs().amax(-1)          # [B,R,R] set match
+        assert (d.amin(dim=2) <= 1e-3).float().mean().item() > 0.98, "RoI set diverged beyond isolated discrete flips"
+        # head fed the oracle's feature map and the oracle's RoIs
+        cl, sc = model.head(feat.to(dev), ref_out[2].to(dev), ref_out[3].to(dev), tuple(x.shape[2:]))
+        assert (cl.cpu() - ref_out[0]).abs().max().item() < 1e-3
+        assert (sc.cpu() - ref_out[1]).abs().max().item() < 1e-3
+        assert torch.equal(sc.cpu().argmax(-1), ref_out[1].argmax(-1))
+
+
+def test_proposal_creator_single_image_surface(dev):
+    """ProposalCreator.__call__(loc, score, anchor, img_size, scale) as the reference exposes it."""
+    from two_stage_object_detection_amd.nets.rpn import ProposalCreator
+    g = torch.Generator().manual_seed(5)
+    base = oracle.generate_basic_anchor()
+    anchor = oracle.enumerate_shifted_anchor(base, 16, 20, 28)
+    loc = torch.randn(anchor.shape[0], 4, generator=g) * 0.3
+    score = torch.rand(anchor.shape[0], generator=g)
+    for mode in ("training", "train"):
+        ref, d = oracle.proposal_layer(loc, score, anchor, (3, 320, 448), mode=mode, return_debug=True)
+        got = ProposalCreator(mode)(loc.to(dev), score.to(dev), anchor.to(dev), (3, 320, 448), 1.0)
+        assert got.shape == ref.shape == ((600, 4) if mode == "train" else (300, 4))
+        assert (got.cpu() - ref).abs().max().item() < 1e-3
+    with pytest.raises(IndexError):                       # pad needs more candidates than exist (Q4)
+        ProposalCreator("training")(loc[:40].to(dev), score[:40].to(dev), anchor[:40].to(dev), (3, 320, 448))
+
+
+# ----------------------------------------------------------------------------- end to end
+@pytest.mark.parametrize("backbone,shape,ncls", [("resnet50", (2, 3, 320, 448), 20), ("hardnet39", (2, 3, 320, 448), 20),
+                                                 ("hardnet68", (1, 3, 256, 320), 20), ("resnet50", (1, 3, 800, 1333), 80)])
+def test_detector_end_to_end(dev, synth, backbone, shape, ncls):
+    from two_stage_object_detection_amd.testing import compare_detector_outputs
+    model, sd = synth(backbone, ncls)
+    x = _img(shape)
+    with torch.inference_mode():
+        ref = oracle.detector_forward(sd, x, backbone=backbone)
+        got = [o.cpu() for o in model(x.to(dev))]
+        model.raise_if_error()
+    rep = compare_detector_outputs(got, ref)
+    print(backbone, shape, rep)
+    # isolated discrete flips are tolerated (reported), everything that is matched must meet the bar
+    assert rep["ok"], rep
+    if backbone == "resnet50":
+        assert rep["rows_positional_mismatch"] == 0 and rep["rows_unmatched"] == 0, rep   # well-separated scores: exact
+
+
+def test_forward_modes_surface(dev, synth):
+    """mode = extractor / rpn / head of nets/frcnn.py:41-54 (with the 5-tuple the reference intends)."""
+    model, sd = synth("resnet50")
+    x = _img((1, 3, 224, 224)).to(dev)
+    with torch.inference_mode():
+        feat = model(x, mode="extractor")
+        assert feat.shape == (1, 2048, 7, 7)
+        r = model((feat, (3, 224, 224)), mode="rpn")
+        assert len(r) == 5 and r[2].shape == (1, 300, 4) and r[3].dtype == torch.int32
+        cl, sc = model((feat, r[2], r[3], (224, 224)), mode="head")
+        full = model(x)
+        assert torch.equal(full[2], r[2]) and torch.equal(full[0], cl) and torch.equal(full[1], sc)   # deterministic
+        det = model.detections(x)
+        assert det.shape == (1, 300, 6)
+
+
+def test_hip_graph_replay_is_bit_identical(dev, synth):
+    model, sd = synth("resnet50")
+    x = _img((1, 3, 256, 320)).to(dev)
+    with torch.inference_mode():
+        eager = [o.clone() for o in model(x)]
+        plan = model.extractor._plan_for(x)
+        plan.capture()
+        replay = [o.clone() for o in model(x)]
+        plan.graph = None
+    for a, b in zip(eager, replay):
+        assert torch.equal(a, b)

@@ -14,7 +14,7 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libtsod.so")
 
-TSOD_MAX_SEGMENTS = 8
+TSOD_MAX_SEGMENTS = 16
 ACT_NONE, ACT_PRELU, ACT_RELU6, ACT_RELU = 0, 1, 2, 3
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4
 TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "64x128"}
@@ -58,6 +58,8 @@ _SIGNATURES = {
     "tsod_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "tsod_rpn_decode_f32": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tsod_proposal_decode_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_void_p,
+                                         c_void_p, c_void_p]),
     "tsod_enumerate_anchors_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "tsod_loc2bbox_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "tsod_sort_topk_desc_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,

@@ -101,6 +101,24 @@ loc2bbox_kernel(const float *__restrict__ src, const float *__restrict__ loc, lo
     }
 }
 
+__global__ void __launch_bounds__(256)
+proposal_decode_kernel(const float *__restrict__ anchor, const float *__restrict__ loc, const float *__restrict__ score,
+                       long n, float clamp_x, float clamp_y, float min_size, float *__restrict__ boxes,
+                       float *__restrict__ keys) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const float4 a = reinterpret_cast<const float4 *>(anchor)[t];
+        const float4 l = reinterpret_cast<const float4 *>(loc)[t];
+        Box o = decode_box(a.x, a.y, a.z, a.w, l.x, l.y, l.z, l.w);
+        o.x1 = clampf(o.x1, 0.f, clamp_x);
+        o.x2 = clampf(o.x2, 0.f, clamp_x);
+        o.y1 = clampf(o.y1, 0.f, clamp_y);
+        o.y2 = clampf(o.y2, 0.f, clamp_y);
+        const bool ok = ((o.x2 - o.x1) >= min_size) && ((o.y2 - o.y1) >= min_size);
+        reinterpret_cast<float4 *>(boxes)[t] = make_float4(o.x1, o.y1, o.x2, o.y2);
+        keys[t] = ok ? score[t] : -INFINITY;
+    }
+}
+
 // One wave per RoI: arg-max over n_class logits (first maximum wins), then loc2bbox with the
 // 4 offsets of that class (nets/frcnn_training.py:311-319).
 __global__ void __launch_bounds__(256)
@@ -176,5 +194,16 @@ extern "C" int tsod_loc2bbox_f32(const float *src, const float *loc, int64_t n, 
     TSOD_REQUIRE(tsod_aligned16(src) && tsod_aligned16(loc) && tsod_aligned16(out), TSOD_ERR_ALIGNMENT);
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(loc2bbox_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), src, loc, (long)n, out);
+    return tsod_launch_status();
+}
+
+extern "C" int tsod_proposal_decode_f32(const float *anchor, const float *loc, const float *score, int64_t n,
+                                        float clamp_x, float clamp_y, float min_size, float *boxes, float *keys,
+                                        tsod_stream_t stream) {
+    TSOD_REQUIRE(anchor && loc && score && boxes && keys && n > 0, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(tsod_aligned16(anchor) && tsod_aligned16(loc) && tsod_aligned16(boxes), TSOD_ERR_ALIGNMENT);
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(proposal_decode_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), anchor, loc, score,
+                       (long)n, clamp_x, clamp_y, min_size, boxes, keys);
     return tsod_launch_status();
 }

@@ -1,0 +1,236 @@
+"""Host-side execution engine: weight folding/packing, activation buffers, and a static launch plan.
+
+A *plan* is the list of C-ABI calls (pre-bound ctypes arguments) that one forward of a module makes
+for one input geometry.  Building it does all host work once (shape arithmetic, descriptor structs,
+buffer assignment, tile selection); running it is a loop of ``libtsod`` launches on the current
+HIP stream with no host synchronisation, so a plan can be captured into a HIP graph
+(``Plan.capture`` uses ``torch.cuda.CUDAGraph`` purely as the stream-capture plumbing).
+
+Data layout in HBM: every activation is NHWC f32, channel pitch a multiple of 4, 16-byte aligned.
+"""
+from __future__ import annotations
+
+from ctypes import byref, c_int32
+from typing import Callable, Sequence
+
+import torch
+
+from . import _ffi
+from ._ffi import (ACT_NONE, ACT_PRELU, ACT_RELU, ACT_RELU6, TILE_NAMES, ConvDesc, TsodError, check, lib,
+                   make_conv_desc, ptr, stream_ptr)
+
+
+# --------------------------------------------------------------------------- weights
+def fold_bn(bn: torch.nn.BatchNorm2d):
+    """eval-mode BatchNorm as y = x*scale + shift (f64 on the host, rounded once to f32)."""
+    var = bn.running_var.detach().double().cpu()
+    mean = bn.running_mean.detach().double().cpu()
+    gamma = bn.weight.detach().double().cpu() if bn.affine else torch.ones_like(var)
+    beta = bn.bias.detach().double().cpu() if bn.affine else torch.zeros_like(var)
+    scale = gamma / torch.sqrt(var + bn.eps)
+    shift = beta - mean * scale
+    return scale.float(), shift.float()
+
+
+class PackedConv:
+    """A dense conv (+ folded BN or bias, + activation) in the layout tsod_conv2d_f32 consumes."""
+
+    def __init__(self, weight: torch.Tensor, device, *, bn=None, bias=None, stride=1, pad=0, act=ACT_NONE, slope=0.0,
+                 cin_pad=None, kw_pad=None, cout_pad=None):
+        from . import hip_ops
+        w = weight.detach().to(device=device, dtype=torch.float32)
+        self.cout, self.cin_src, self.kh, self.kw_logical = w.shape
+        self.w = hip_ops.pack_conv_weight(w, cin_pad, kw_pad)
+        self.cin, self.kw = self.w.shape[3], self.w.shape[2]
+        self.stride, self.pad, self.act, self.slope = stride, pad, act, float(slope)
+        scale = shift = None
+        if bn is not None:
+            scale, shift = fold_bn(bn)
+        elif bias is not None:
+            shift = bias.detach().float().cpu()
+        self.scale = None if scale is None else scale.to(device)
+        self.shift = None if shift is None else shift.to(device)
+
+    def out_hw(self, H, W):
+        return ((H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw_logical) // self.stride + 1)
+
+
+def prelu_slope(m: torch.nn.PReLU) -> float:
+    if m.weight.numel() != 1:
+        raise TsodError("only single-parameter nn.PReLU is supported (what the reference uses)")
+    return float(m.weight.detach().cpu().item())
+
+
+# --------------------------------------------------------------------------- buffers
+class BufferPool:
+    """Activation buffers reused across layers of one plan (liveness is explicit: alloc / release)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._free: dict[int, list[torch.Tensor]] = {}
+        self.total_bytes = 0
+
+    def alloc(self, shape: Sequence[int], dtype=torch.float32) -> torch.Tensor:
+        n = 1
+        for s in shape:
+            n *= int(s)
+        key = (n, dtype)
+        lst = self._free.get(key)
+        if lst:
+            return lst.pop().view(*shape)
+        self.total_bytes += n * (4 if dtype in (torch.float32, torch.int32) else 8)
+        return torch.empty(n, dtype=dtype, device=self.device).view(*shape)
+
+    def release(self, t: torch.Tensor) -> None:
+        self._free.setdefault((t.numel(), t.dtype), []).append(t.reshape(-1))
+
+
+def _merge_adjacent(segs):
+    """Fuse channel segments that are contiguous in the pixel (same K order, fewer descriptor entries)."""
+    out = []
+    for off, ln in segs:
+        if out and out[-1][0] + out[-1][1] == off:
+            out[-1] = (out[-1][0], out[-1][1] + ln)
+        else:
+            out.append((off, ln))
+    return out
+
+
+# --------------------------------------------------------------------------- plan
+class ConvStep:
+    __slots__ = ("desc", "args", "name", "flops", "ws_bytes")
+
+
+class Plan:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.pool = BufferPool(self.device)
+        self.steps: list[list] = []          # [cfunc, [args...]]
+        self.conv_steps: list[ConvStep] = []
+        self.keep: list = []                 # keeps descriptors / tensors alive
+        self._ws_slots: list[tuple[list, int, int, int]] = []   # (args, ptr index, size index, bytes)
+        self.workspace: torch.Tensor | None = None
+        self.graph = None
+        self.flops = 0
+
+    # -- building ---------------------------------------------------------------------------
+    def call(self, fn, *args, keep=()):
+        self.steps.append([fn, list(args)])
+        self.keep.extend(keep)
+        return self.steps[-1]
+
+    def conv(self, pc: PackedConv, x: torch.Tensor, out: torch.Tensor, *, segs=None, out_off=0, residual=None,
+             name="conv", tile=0, split_k=0):
+        """x [N,H,W,P] -> out [N,OH,OW,Pout] (channel slice [out_off, out_off+Cout))."""
+        N, H, W, P = x.shape
+        OH, OW = pc.out_hw(H, W)
+        assert tuple(out.shape[:3]) == (N, OH, OW), (out.shape, (N, OH, OW))
+        segs = [(0, pc.cin)] if segs is None else _merge_adjacent(segs)
+        d = make_conv_desc(N=N, H=H, W=W, in_pitch=P, segs=segs, Cout=pc.cout, out_pitch=out.shape[3], out_off=out_off,
+                           KH=pc.kh, KW=pc.kw, stride=pc.stride, pad_h=pc.pad, pad_w=pc.pad, OH=OH, OW=OW, act=pc.act,
+                           slope=pc.slope, res_pitch=0 if residual is None else residual.shape[3], res_off=0,
+                           tile=tile, split_k=split_k)
+        args = [byref(d), ptr(x), ptr(pc.w), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out), 0, 0]
+        self.steps.append([lib().tsod_conv2d_f32, args])
+        st = ConvStep()
+        st.desc, st.args, st.name = d, args, name
+        st.flops = 2 * N * OH * OW * pc.cout * pc.kh * pc.kw_logical * pc.cin_src
+        st.ws_bytes = 0
+        self.conv_steps.append(st)
+        self.flops += st.flops
+        self.keep.extend([d, x, out, pc, residual])
+        return out
+
+    def finalize(self):
+        """Size the shared split-K workspace (stream order makes sharing safe) and bind it."""
+        need = 256
+        for st in self.conv_steps:
+            st.ws_bytes = lib().tsod_conv2d_workspace_bytes(byref(st.desc))
+            need = max(need, st.ws_bytes)
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        for st in self.conv_steps:
+            st.args[7] = ptr(self.workspace)
+            st.args[8] = self.workspace.numel()
+        self.graph = None
+        return self
+
+    # -- running ----------------------------------------------------------------------------
+    def launch(self):
+        s = stream_ptr()
+        for fn, args in self.steps:
+            rc = fn(*args, s)
+            if rc != 0:
+                check(rc, getattr(fn, "__name__", "tsod call"))
+
+    def run(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.launch()
+
+    def capture(self):
+        """Record the plan into a HIP graph (one graph launch per forward afterwards)."""
+        torch.cuda.synchronize(self.device)
+        side = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(side):
+            self.launch()                      # warm-up outside capture
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            self.launch()
+        self.graph = g
+        return self
+
+    # -- tile autotuning ----------------------------------------------------------------------
+    def autotune(self, reps: int = 3, verbose: bool = False):
+        """Measure every (tile, split_k) candidate of every conv step on the real buffers with HIP
+        events and keep the fastest.  Purely a speed choice: every candidate computes the same sums
+        in the same k order per slab; only slab boundaries move."""
+        self.graph = None
+        big = torch.empty(512 << 20, dtype=torch.uint8, device=self.device)   # scratch for any split
+        results = []
+        for st in self.conv_steps:
+            d = st.desc
+            K = d.KH * d.KW * sum(d.seg_len[i] for i in range(d.n_seg))
+            ksteps = (K + 31) // 32
+            M = d.N * d.OH * d.OW
+            cands = []
+            for tile in (1, 2, 3, 4):
+                for split in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+                    if split > 1 and (ksteps // split < 2 or split * M * d.Cout * 4 > big.numel()):
+                        continue
+                    cands.append((tile, split))
+            best = None
+            args = list(st.args)
+            args[7], args[8] = ptr(big), big.numel()
+            for tile, split in cands:
+                d.tile, d.split_k = tile, split
+                s = stream_ptr()
+                lib().tsod_conv2d_f32(*args, s)          # warm
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    rc = lib().tsod_conv2d_f32(*args, s)
+                e1.record()
+                e1.synchronize()
+                check(rc, "autotune conv")
+                t = e0.elapsed_time(e1) / reps
+                if best is None or t < best[0]:
+                    best = (t, tile, split)
+            d.tile, d.split_k = best[1], best[2]
+            results.append((st.name, best[0], best[1], best[2], st.flops))
+            if verbose:
+                print(f"  {st.name:34s} {TILE_NAMES[best[1]]:8s} split {best[2]:2d}  {best[0] * 1e3:8.1f} us "
+                      f"{st.flops / best[0] / 1e9:7.1f} TF/s")
+        del big
+        self.finalize()
+        return results
+
+    def tile_choices(self):
+        out = []
+        for st in self.conv_steps:
+            t, s = c_int32(0), c_int32(0)
+            lib().tsod_conv2d_resolve(byref(st.desc), byref(t), byref(s))
+            out.append((st.name, t.value, s.value))
+        return out

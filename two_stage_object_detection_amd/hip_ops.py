@@ -170,6 +170,18 @@ def rpn_decode(locs: torch.Tensor, scores: torch.Tensor, anchor_base: torch.Tens
     return boxes, fg, keys, anchors
 
 
+def proposal_decode(anchor: torch.Tensor, loc: torch.Tensor, score: torch.Tensor, clamp_x, clamp_y, min_size):
+    """anchor [n,4], loc [n,4], score [n] -> boxes [n,4] (decoded + clamped), keys [n] (-inf = too small)."""
+    require_cuda(loc, "proposal_decode")
+    anchor, loc, score = anchor.float().contiguous(), loc.contiguous(), score.contiguous()
+    n = loc.shape[0]
+    boxes = torch.empty((n, 4), dtype=torch.float32, device=loc.device)
+    keys = torch.empty((n,), dtype=torch.float32, device=loc.device)
+    check(lib().tsod_proposal_decode_f32(ptr(anchor), ptr(loc), ptr(score), n, float(clamp_x), float(clamp_y),
+                                         float(min_size), ptr(boxes), ptr(keys), stream_ptr()), "proposal_decode")
+    return boxes, keys
+
+
 def enumerate_anchors(anchor_base: torch.Tensor, feat_stride: int, height: int, width: int) -> torch.Tensor:
     require_cuda(anchor_base, "enumerate_anchors")
     base = anchor_base.contiguous()

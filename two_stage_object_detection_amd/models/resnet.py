@@ -1,0 +1,205 @@
+"""ResNet backbones with the reference's module surface (models/resnet.py of the reference) and a
+HIP execution path.
+
+Same class names, constructor signatures, sub-module names and parameter shapes as the reference
+(``conv1/bn1/relu/maxpool/layer{1..4}[/avgpool/fc]``, blocks ``conv{1,2,3}/bn{1,2,3}/relu/downsample``),
+so its checkpoints load with ``strict=True`` and ``torch.manual_seed(s)`` reproduces the same
+initial weights (sub-modules are created, and the Kaiming fan_out pass applied, in the same order:
+reference models/resnet.py:94-109).
+
+The nn.Conv2d / nn.BatchNorm2d / nn.PReLU children are parameter containers only.  ``forward``
+compiles a launch plan of fused conv+BN+PReLU(+residual) implicit-GEMM kernels (engine.Plan) for the
+input geometry and runs it on the GPU; there is no eager / CPU path.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import hip_ops
+from .._ffi import ACT_NONE, ACT_PRELU, TsodError, lib, ptr, require_cuda
+from ..engine import PackedConv, Plan, prelu_slope
+
+
+def _conv(cin, cout, k, stride=1, pad=0, groups=1):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, groups=groups, bias=False)
+
+
+class _ResidualBlock(nn.Module):
+    """Shared machinery of the two block types: a list of (conv, bn) stages, one shared PReLU."""
+    expansion = 1
+    _stage_names: tuple = ()
+
+    def _emit(self, plan: Plan, x: torch.Tensor, name: str) -> torch.Tensor:
+        dev = plan.device
+        slope = prelu_slope(self.relu)
+        identity = x
+        if self.downsample is not None:
+            ds_conv, ds_bn = self.downsample[0], self.downsample[1]
+            pc = PackedConv(ds_conv.weight, dev, bn=ds_bn, stride=ds_conv.stride[0], act=ACT_NONE)
+            oh, ow = pc.out_hw(x.shape[1], x.shape[2])
+            identity = plan.conv(pc, x, plan.pool.alloc((x.shape[0], oh, ow, pc.cout)), name=f"{name}.downsample")
+        cur = x
+        last = len(self._stage_names) - 1
+        for i, (cname, bname) in enumerate(self._stage_names):
+            conv, bn = getattr(self, cname), getattr(self, bname)
+            if conv.groups != 1:
+                raise TsodError("grouped 3x3 convolutions (ResNeXt) have no HIP kernel in this build")
+            pc = PackedConv(conv.weight, dev, bn=bn, stride=conv.stride[0], pad=conv.padding[0], act=ACT_PRELU, slope=slope)
+            oh, ow = pc.out_hw(cur.shape[1], cur.shape[2])
+            out = plan.pool.alloc((cur.shape[0], oh, ow, pc.cout))
+            plan.conv(pc, cur, out, residual=identity if i == last else None, name=f"{name}.{cname}")
+            if cur is not x:
+                plan.pool.release(cur)
+            cur = out
+        if identity is not x:
+            plan.pool.release(identity)
+        return cur
+
+
+class BasicBlock(_ResidualBlock):
+    expansion = 1
+    _stage_names = (("conv1", "bn1"), ("conv2", "bn2"))
+
+    def __init__(self, in_channel, out_channel, stride=1, downsample=None, **kwargs):
+        super().__init__()
+        self.conv1 = _conv(in_channel, out_channel, 3, stride, 1)
+        self.bn1 = nn.BatchNorm2d(out_channel)
+        self.relu = nn.PReLU()
+        self.conv2 = _conv(out_channel, out_channel, 3, 1, 1)
+        self.bn2 = nn.BatchNorm2d(out_channel)
+        self.downsample = downsample
+
+
+class Bottleneck(_ResidualBlock):
+    expansion = 4
+    _stage_names = (("conv1", "bn1"), ("conv2", "bn2"), ("conv3", "bn3"))
+
+    def __init__(self, in_channel, out_channel, stride=1, downsample=None, groups=1, width_per_group=64):
+        super().__init__()
+        width = int(out_channel * (width_per_group / 64.)) * groups
+        self.conv1 = _conv(in_channel, width, 1)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = _conv(width, width, 3, stride, 1, groups)      # stride on the 3x3 (v1.5)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = _conv(width, out_channel * self.expansion, 1)
+        self.bn3 = nn.BatchNorm2d(out_channel * self.expansion)
+        self.relu = nn.PReLU()
+        self.downsample = downsample
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, blocks_num, num_classes=25, include_top=True, groups=1, width_per_group=64):
+        super().__init__()
+        self.include_top = include_top
+        self.in_channel = 64
+        self.groups = groups
+        self.width_per_group = width_per_group
+        self.conv1 = _conv(3, 64, 7, 2, 3)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.PReLU()
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        for i, (ch, n, stride) in enumerate(zip((64, 128, 256, 512), blocks_num, (1, 2, 2, 2)), start=1):
+            setattr(self, f"layer{i}", self._make_layer(block, ch, n, stride))
+        if include_top:
+            self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+            self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self._plans: dict = {}
+        self.out_channels = 512 * block.expansion
+
+    def _make_layer(self, block, channel, block_num, stride=1):
+        out_ch = channel * block.expansion
+        downsample = None
+        if stride != 1 or self.in_channel != out_ch:
+            downsample = nn.Sequential(_conv(self.in_channel, out_ch, 1, stride), nn.BatchNorm2d(out_ch))
+        blocks = [block(self.in_channel, channel, downsample=downsample, stride=stride, groups=self.groups,
+                        width_per_group=self.width_per_group)]
+        self.in_channel = out_ch
+        blocks += [block(out_ch, channel, groups=self.groups, width_per_group=self.width_per_group)
+                   for _ in range(1, block_num)]
+        return nn.Sequential(*blocks)
+
+    # -- plan ---------------------------------------------------------------------------------
+    def invalidate_packed(self):
+        """Drop compiled plans (call after changing weights in place)."""
+        self._plans = {}
+
+    def _apply(self, fn, *a, **k):
+        self._plans = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._plans = {}
+        return super().load_state_dict(*a, **k)
+
+    def build_plan(self, N, H, W, device) -> Plan:
+        """Launch plan for a [N,3,H,W] input: NCHW->NHWC4, 7x7 stem as a 7x8x4 implicit GEMM with
+        BN+PReLU, 3x3/s2 max pool, then the residual stages."""
+        plan = Plan(device)
+        x4 = plan.pool.alloc((N, H, W, 4))
+        plan.input_nhwc = x4
+        stem = PackedConv(self.conv1.weight, device, bn=self.bn1, stride=2, pad=3, act=ACT_PRELU,
+                          slope=prelu_slope(self.relu), cin_pad=4, kw_pad=8)
+        oh, ow = stem.out_hw(H, W)
+        s_out = plan.conv(stem, x4, plan.pool.alloc((N, oh, ow, 64)), name="conv1")
+        ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
+        cur = plan.pool.alloc((N, ph, pw, 64))
+        plan.call(lib().tsod_maxpool3x3s2_f32, ptr(s_out), N, oh, ow, 64, 64, ptr(cur), 64, keep=(s_out, cur))
+        plan.pool.release(s_out)
+        for li in range(1, 5):
+            for bi, blk in enumerate(getattr(self, f"layer{li}")):
+                nxt = blk._emit(plan, cur, f"layer{li}.{bi}")
+                plan.pool.release(cur)
+                cur = nxt
+        plan.output_nhwc = cur
+        return plan.finalize()
+
+    def _plan_for(self, x: torch.Tensor) -> Plan:
+        require_cuda(x, "ResNet.forward")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise TsodError(f"expected [N,3,H,W], got {tuple(x.shape)}")
+        key = (tuple(x.shape), x.device)
+        plan = self._plans.get(key)
+        if plan is None:
+            if self.training:
+                raise TsodError("the HIP path implements the inference forward only: call .eval() first")
+            plan = self.build_plan(x.shape[0], x.shape[2], x.shape[3], x.device)
+            self._plans[key] = plan
+        return plan
+
+    def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+        """[N,3,H,W] -> NHWC feature [N,H/32,W/32,C] (plan-owned buffer, valid until the next forward)."""
+        plan = self._plan_for(x)
+        x = x.contiguous()
+        N, _, H, W = x.shape
+        hip_ops.check(lib().tsod_nchw_to_nhwc_f32(ptr(x), N, 3, H, W, ptr(plan.input_nhwc), 4, 4, hip_ops.stream_ptr()),
+                      "nchw_to_nhwc")
+        plan.run()
+        return plan.output_nhwc
+
+    def forward(self, x):
+        feat = self.forward_nhwc(x)
+        if self.include_top:
+            raise TsodError("include_top=True (avgpool + fc classifier) is outside the detector forward path; "
+                            "build with include_top=False")
+        return hip_ops.nhwc_to_nchw(feat)
+
+
+def resnet34(num_classes=25, include_top=True):
+    return ResNet(BasicBlock, [3, 4, 6, 3], num_classes=num_classes, include_top=include_top)
+
+
+def resnet50(num_classes=25, include_top=True):
+    return ResNet(Bottleneck, [3, 4, 6, 3], num_classes=num_classes, include_top=include_top)
+
+
+def resnet101(num_classes=25, include_top=True):
+    return ResNet(Bottleneck, [3, 4, 23, 3], num_classes=num_classes, include_top=include_top)
+
+
+def resnext50_32x4d(num_classes=25, include_top=True):
+    return ResNet(Bottleneck, [3, 4, 6, 3], num_classes=num_classes, include_top=include_top, groups=32,
+                  width_per_group=4)

@@ -1,0 +1,109 @@
+"""Faster R-CNN top module with the reference's surface (nets/frcnn.py) on the HIP path.
+
+The reference file is dead code as written (its ctor raises TypeError, its forward unpacks 5 values
+from an RPN that returns 4); the semantics here are those of the one working wiring,
+FasterRCNNTrainer (nets/frcnn_training.py:203-217, 251-260, 289-298):
+
+  * the RPN receives img_size = x.shape[1:] = (C,H,W)   (frcnn_training.py:252, quirk Q1)
+  * the head receives img_size = x.shape[2:] = (H,W)     (nets/frcnn.py:33,39, quirk Q2)
+  * roi_indices = arange(B), int32                        (frcnn_training.py:291, quirk Q6)
+
+Added, non-breaking: ``backbone`` = "hardnet39" (the reference's default extractor) | "hardnet68" |
+"resnet50" (resnet50(include_top=False): stride 32, 2048 channels - the composition BASELINE names).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import hip_ops
+from .._ffi import TsodError, require_cuda
+from .classify import HarNetRoIHead
+from .rpn import RegionProposalNetwork
+from ..models.hardnet import HarDNetFeatureExtraction, HarNetClassifier
+
+
+def _make_extractor(backbone):
+    if backbone == "resnet50":
+        from ..models.resnet import resnet50
+        return resnet50(include_top=False), 2048, 32
+    if backbone in ("hardnet39", "hardnet68", "hardnet85"):
+        return HarDNetFeatureExtraction(depth_wise=True, arch=int(backbone[-2:])), 512, 16
+    raise ValueError(f"unknown backbone {backbone!r}")
+
+
+class FasterRCNN(nn.Module):
+    def __init__(self, num_classes, mode="training", feat_stride=16, anchor_scales=[8, 16, 32], ratios=[0.5, 1, 2],
+                 backbone="hardnet39"):
+        super().__init__()
+        self.backbone = backbone
+        self.extractor, feat_ch, native_stride = _make_extractor(backbone)
+        self.classifier = HarNetClassifier()
+        # the reference's default 16 is the HarDNet stride; a stride-32 trunk overrides it
+        self.feat_stride = native_stride if (feat_stride == 16 and native_stride != 16) else feat_stride
+        self.rpn = RegionProposalNetwork(feat_ch, ratios=ratios, anchor_scales=anchor_scales,
+                                         feat_stride=self.feat_stride, mode=mode)
+        self.head = HarNetRoIHead(n_class=num_classes + 1, roi_size=7, spatial_scale=1, classifier=self.classifier,
+                                  in_channels=feat_ch)
+
+    def forward(self, x, scale=1., mode="forward"):
+        if mode == "forward":
+            require_cuda(x, "FasterRCNN.forward")
+            feat = self.extractor.forward_nhwc(x)
+            _, _, rois, _ = self.rpn.forward_nhwc(feat, tuple(x.shape[1:]), scale)
+            roi_indices = torch.arange(x.shape[0], dtype=torch.int32, device=x.device)
+            roi_cls_locs, roi_scores = self.head.forward_nhwc(feat, rois, roi_indices, tuple(x.shape[2:]))
+            return roi_cls_locs, roi_scores, rois, roi_indices
+        elif mode == "extractor":
+            return self.extractor.forward(x)
+        elif mode == "rpn":
+            base_feature, img_size = x
+            rpn_locs, rpn_scores, rois, anchor = self.rpn.forward(base_feature, img_size, scale)
+            roi_indices = torch.arange(base_feature.shape[0], dtype=torch.int32, device=base_feature.device)
+            return rpn_locs, rpn_scores, rois, roi_indices, anchor
+        elif mode == "head":
+            base_feature, rois, roi_indices, img_size = x
+            return self.head.forward(base_feature, rois, roi_indices, img_size)
+        raise ValueError(f"unknown mode {mode!r}")
+
+    def detections(self, x, scale=1.):
+        """[B,R,6] rows (x1,y1,x2,y2, max logit, arg-max class): SURVEY D5 / frcnn_training.py:311-319."""
+        cls_locs, scores, rois, _ = self.forward(x, scale)
+        return hip_ops.detections(cls_locs, scores, rois)
+
+    def make_graphed(self, x_example):
+        """Capture forward + detection records for this input geometry into ONE HIP graph.
+        Returns (run, static_input, static_outputs): copy images into ``static_input`` (or pass them
+        to ``run(x)``), call ``run()``, read ``static_outputs`` = (roi_cls_locs, roi_scores, rois,
+        roi_indices, detections).  torch.cuda.CUDAGraph is only the stream-capture plumbing: every
+        node of the graph is a libtsod kernel."""
+        require_cuda(x_example, "FasterRCNN.make_graphed")
+        static_in = x_example.clone()
+        side = torch.cuda.Stream(x_example.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.inference_mode():
+            for _ in range(2):                                   # builds plans, sizes workspaces
+                outs = self.forward(static_in)
+                hip_ops.detections(outs[0], outs[1], outs[2])
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.inference_mode(), torch.cuda.graph(graph, stream=side):
+            outs = self.forward(static_in)
+            det = hip_ops.detections(outs[0], outs[1], outs[2])
+        static_out = tuple(outs) + (det,)
+
+        def run(x=None):
+            if x is not None:
+                static_in.copy_(x, non_blocking=True)
+            graph.replay()
+            return static_out
+        return run, static_in, static_out
+
+    def raise_if_error(self):
+        """Surface the deferred IndexError of the proposal padding (one device sync)."""
+        self.rpn.raise_if_error()
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()

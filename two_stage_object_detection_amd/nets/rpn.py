@@ -1,0 +1,129 @@
+"""Region proposal network with the reference's module surface (nets/rpn.py) on HIP kernels.
+
+``ProposalCreator`` and ``RegionProposalNetwork`` keep the reference's constructor / call
+signatures, the 4-tuple return of the working code (quirk Q6), the "train" vs "training" mode-string
+behaviour (Q3), the img_size[1] / img_size[2] clamp indexing (Q1) and the duplicate-padding rule
+after NMS (Q4).  The per-image Python loop of the reference (nets/rpn.py:129-137) is replaced by
+batched kernels:
+
+    1x1 convs (implicit GEMM, NHWC out)  ->  tsod_rpn_decode_f32  ->  tsod_sort_topk_desc_f32
+    ->  tsod_nms_f32 (mask + wave scan + pad)
+
+Nothing in the chain synchronises with the host.  The one error the reference can raise here
+(IndexError when the pad needs more candidates than exist) is recorded in a device status word:
+``strict=True`` checks it right away (one sync), otherwise call ``raise_if_error()`` when convenient.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import hip_ops
+from .._ffi import ACT_NONE, TsodError, require_cuda
+from ..engine import PackedConv
+from ..utils._config import load_config
+from ..utils.basic_anchors import generate_basic_anchor
+
+config = load_config()
+device = config["device"]          # kept for surface parity; forward uses x.device (quirk Q12)
+
+
+class ProposalCreator:
+    def __init__(self, mode, nms_iou=0.7, n_train_pre_nms=12000, n_train_post_nms=600, n_test_pre_nms=3000,
+                 n_test_post_nms=300, min_size=16):
+        self.mode = mode
+        self.nms_iou = nms_iou
+        self.n_train_pre_nms = n_train_pre_nms
+        self.n_train_post_nms = n_train_post_nms
+        self.n_test_pre_nms = n_test_pre_nms
+        self.n_test_post_nms = n_test_post_nms
+        self.min_size = min_size
+        self.strict = True
+
+    def counts(self):
+        """(n_pre_nms, n_post_nms): only the literal "train" selects the train numbers."""
+        if self.mode == "train":
+            return self.n_train_pre_nms, self.n_train_post_nms
+        return self.n_test_pre_nms, self.n_test_post_nms
+
+    def select(self, boxes, keys, strict=None):
+        """boxes [B,n,4] decoded+clamped, keys [B,n] (fg score, -inf = filtered) -> rois [B,n_post,4]."""
+        n_pre, n_post = self.counts()
+        if n_pre <= 0:
+            n_pre = min(boxes.shape[1], 16384)
+        counts, _, bs, _ = hip_ops.sort_topk_desc(keys, boxes, n_pre)
+        _, rois, _, status = hip_ops.nms_sorted(bs, counts, self.nms_iou, n_post)
+        self.last_status = status
+        if self.strict if strict is None else strict:
+            self.raise_if_error()
+        return rois
+
+    def raise_if_error(self):
+        st = getattr(self, "last_status", None)
+        if st is not None and int(st.item()) & 1:
+            raise IndexError("proposal padding needs more candidates than survive the min-size filter "
+                             "(the reference raises IndexError at nets/rpn.py:69)")
+
+    def __call__(self, loc, score, anchor, img_size, scale=1.):
+        """One image: loc [A,4], score [A] fg probabilities, anchor [A,4] -> roi [n_post,4]."""
+        require_cuda(loc, "ProposalCreator")
+        boxes, keys = hip_ops.proposal_decode(anchor, loc, score, img_size[1], img_size[2], self.min_size * scale)
+        return self.select(boxes.unsqueeze(0), keys.unsqueeze(0))[0]
+
+
+class RegionProposalNetwork(nn.Module):
+    def __init__(self, in_channels=512, ratios=[0.5, 1, 2], anchor_scales=[8, 16, 32], feat_stride=16,
+                 mode="training"):
+        super().__init__()
+        if isinstance(ratios, int):
+            # legacy call shape RegionProposalNetwork(512, 512, ratios=...) of nets/frcnn.py:16-22 (quirk Q7)
+            raise TypeError("RegionProposalNetwork() got multiple values for argument 'ratios'")
+        self.anchor_base = generate_basic_anchor(anchor_scales=anchor_scales, ratios=ratios)
+        n_anchor = self.anchor_base.shape[0]
+        self.score = nn.Conv2d(in_channels, n_anchor * 2, 1, 1, 0)
+        self.loc = nn.Conv2d(in_channels, n_anchor * 4, 1, 1, 0)
+        self.feat_stride = feat_stride
+        self.proposal_layer = ProposalCreator(mode)
+        self.proposal_layer.strict = False
+        self._packed = None
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    def invalidate_packed(self):
+        self._packed = None
+
+    def _pack(self, dev):
+        if self._packed is None or self._packed[0] != dev:
+            self._packed = (dev,
+                            PackedConv(self.loc.weight, dev, bias=self.loc.bias, act=ACT_NONE),
+                            PackedConv(self.score.weight, dev, bias=self.score.bias, act=ACT_NONE),
+                            torch.as_tensor(self.anchor_base, dtype=torch.float32).to(dev).contiguous())
+        return self._packed[1:]
+
+    def forward_nhwc(self, feat: torch.Tensor, img_size, scale=1.):
+        """feat NHWC [n,h,w,C] -> (rpn_locs [n,h*w*A,4], rpn_scores [n,h*w*A,2], rois [n,n_post,4], anchor [1,h*w*A,4])."""
+        require_cuda(feat, "RegionProposalNetwork")
+        n, h, w, _ = feat.shape
+        pc_loc, pc_score, base = self._pack(feat.device)
+        locs = hip_ops.conv2d_nhwc(feat, pc_loc.w, shift=pc_loc.shift)        # [n,h,w,4A]: already the permuted layout
+        scores = hip_ops.conv2d_nhwc(feat, pc_score.w, shift=pc_score.shift)  # [n,h,w,2A]
+        A = base.shape[0]
+        boxes, _, keys, anchor = hip_ops.rpn_decode(locs.view(n * h * w, 4 * A), scores.view(n * h * w, 2 * A), base, n, h,
+                                                    w, self.feat_stride, img_size[1], img_size[2],
+                                                    self.proposal_layer.min_size * scale, want_anchors=True)
+        rois = self.proposal_layer.select(boxes, keys)
+        return locs.view(n, -1, 4), scores.view(n, -1, 2), rois, anchor.unsqueeze(0)
+
+    def forward(self, x, img_size, scale=1.):
+        """x NCHW [n,C,h,w] (the reference's layout)."""
+        require_cuda(x, "RegionProposalNetwork")
+        return self.forward_nhwc(hip_ops.nchw_to_nhwc(x), img_size, scale)
+
+    def raise_if_error(self):
+        self.proposal_layer.raise_if_error()

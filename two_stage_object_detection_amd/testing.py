@@ -1,0 +1,82 @@
+"""Synthetic-weight construction and output comparison used by tests/, bench.py and smoke().
+
+No oracle import here: this module only builds a model and compares two sets of tensors.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def synthetic_detector(backbone="resnet50", num_classes=80, seed=0, mode="training", rpn_loc_gain=None,
+                       rpn_score_gain=None, head_gain=None, calibrate_hw=None):
+    """The detector with seeded random-init weights of the reference architecture:
+    ``torch.manual_seed(seed)`` then modules constructed in reference order (ResNet: Kaiming fan_out on
+    every conv, BN identity, PReLU 0.25; HarDNet / RPN / head: PyTorch defaults).
+
+    With random init the trunk's activations grow to abs-max ~100 (ResNet-50), which would saturate
+    the RPN softmax and exp() of the box decode; the RPN / head weights are therefore scaled by fixed
+    gains so that fg probabilities and box offsets are in the range a trained detector produces
+    (loc std ~0.3, logit std ~2).  Gains are constants (no data pass), so weights depend on the seed only.
+    Returns (model on CPU in eval mode, CPU state_dict with the reference's key names)."""
+    from .nets.frcnn import FasterRCNN
+    torch.manual_seed(seed)
+    model = FasterRCNN(num_classes, mode=mode, backbone=backbone).eval()
+    defaults = {"resnet50": (0.03, 0.15, 0.05), "hardnet39": (0.75, 8.0, 2.0), "hardnet68": (0.75, 8.0, 2.0),
+                "hardnet85": (0.75, 8.0, 2.0)}[backbone]
+    gl = defaults[0] if rpn_loc_gain is None else rpn_loc_gain
+    gs = defaults[1] if rpn_score_gain is None else rpn_score_gain
+    gh = defaults[2] if head_gain is None else head_gain
+    with torch.no_grad():
+        for conv, g in ((model.rpn.loc, gl), (model.rpn.score, gs)):
+            conv.weight.mul_(g)
+            conv.bias.mul_(g)
+        for lin in (model.head.cls_loc, model.head.score):
+            lin.weight.mul_(gh)
+            lin.bias.mul_(gh)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return model, sd
+
+
+def compare_detector_outputs(got, ref, atol=1e-3):
+    """got / ref: (roi_cls_locs [B,R,4n], roi_scores [B,R,n], rois [B,R,4], roi_indices [B]) on CPU.
+
+    Bars (north star): boxes and scores within ``atol`` absolute, arg-max class indices bit-exact.
+    Rows are first compared position-wise (``rows_positional_mismatch``).  A discrete decision that
+    flips between the two f32 pipelines (two scores closer than their rounding noise swap in the
+    sort; an IoU lands within an ulp of the threshold) reorders or shifts the RoI list without changing
+    what is computed per RoI, so rows are then matched as SETS per image (nearest reference RoI within
+    ``atol``); every matched pair must meet the bars, and ``rows_unmatched`` counts RoIs that exist on
+    one side only."""
+    g_locs, g_scores, g_rois, g_idx = got
+    r_locs, r_scores, r_rois, r_idx = ref
+    rep = {"shapes_equal": all(tuple(a.shape) == tuple(b.shape) for a, b in zip(got, ref))}
+    if not rep["shapes_equal"]:
+        rep["ok"] = False
+        rep["shapes"] = [(tuple(a.shape), tuple(b.shape)) for a, b in zip(got, ref)]
+        return rep
+    B, R, _ = g_rois.shape
+    rep["roi_indices_equal"] = bool(torch.equal(g_idx.cpu().long(), r_idx.cpu().long()))
+    rep["rows"] = B * R
+    rep["rows_positional_mismatch"] = int(((g_rois - r_rois).abs().amax(dim=-1) > atol).sum())
+    unmatched, max_roi, max_score, max_loc, cls_bad = 0, 0.0, 0.0, 0.0, 0
+    for b in range(B):
+        d = (g_rois[b].unsqueeze(1) - r_rois[b].unsqueeze(0)).abs().amax(-1)      # [R,R]
+        # prefer the same position when it matches (padding duplicates make rows non-unique)
+        diag = torch.arange(R)
+        best = d.argmin(dim=1)
+        best = torch.where(d[diag, diag] <= atol, diag, best)
+        ok = d[diag, best] <= atol
+        unmatched += int((~ok).sum())
+        if ok.any():
+            gi, ri = diag[ok], best[ok]
+            max_roi = max(max_roi, float(d[gi, ri].max()))
+            max_score = max(max_score, float((g_scores[b, gi] - r_scores[b, ri]).abs().max()))
+            max_loc = max(max_loc, float((g_locs[b, gi] - r_locs[b, ri]).abs().max()))
+            cls_bad += int((g_scores[b, gi].argmax(-1) != r_scores[b, ri].argmax(-1)).sum())
+    rep.update(rows_unmatched=unmatched, max_abs_roi=max_roi, max_abs_score=max_score, max_abs_cls_loc=max_loc,
+               class_mismatch=cls_bad)
+    top2 = r_scores.topk(2, dim=-1).values
+    rep["min_top2_logit_gap"] = float((top2[..., 0] - top2[..., 1]).min())
+    rep["ok"] = bool(rep["roi_indices_equal"] and unmatched <= max(2, (B * R) // 100) and cls_bad == 0
+                     and max_score <= atol and max_loc <= atol and max_roi <= atol)
+    return rep
