@@ -70,7 +70,8 @@ def conv_event_times(plan, reps=5):
 
 def cpu_baseline(sd, backbone, x_cpu, reps):
     import oracle
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box exposes all host cores but grants this job a 16-core share (worker pools must be sized to it)
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("TSOD_CPU_THREADS", "16"))))
     with torch.inference_mode():
         oracle.detector_forward(sd, x_cpu, backbone=backbone)           # warm-up
         ts = []

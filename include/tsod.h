@@ -80,7 +80,9 @@ typedef struct tsod_conv2d_desc {
     int32_t res_pitch;     /* residual pixel pitch (ignored when residual == NULL) */
     int32_t res_off;       /* residual channel offset */
     int32_t tile;          /* TSOD_TILE_*; AUTO = built-in heuristic */
-    int32_t split_k;       /* >=1 explicit K split; 0 = heuristic */
+    int32_t split_k;       /* 1 = whole tiles only; S > 1 = every tile cut into S K-slices; -1 = hybrid (full
+                              chip-waves of whole tiles, left-over tiles K-sliced to fill the last wave);
+                              0 = built-in cost model chooses */
 } tsod_conv2d_desc;
 
 /* Packed weight layout Wp: [Cout][KH][KW][Cin] f32 (k = (kh*KW + kw)*Cin + ci, ci running over
@@ -90,7 +92,7 @@ typedef struct tsod_conv2d_desc {
 int tsod_pack_conv_weight_f32(const float *w_oihw, int32_t Cout, int32_t Cin_src, int32_t KH, int32_t KW_src,
                               int32_t Cin, int32_t KW, float *w_packed, tsod_stream_t stream);
 
-/* Bytes of workspace tsod_conv2d_f32 needs for this descriptor (0 unless K is split). */
+/* Bytes of workspace tsod_conv2d_f32 needs for this descriptor (0 unless some tile is K-sliced). */
 size_t tsod_conv2d_workspace_bytes(const tsod_conv2d_desc *d);
 /* Resolve TSOD_TILE_AUTO / split_k == 0 to the concrete choice the heuristic makes. */
 int tsod_conv2d_resolve(const tsod_conv2d_desc *d, int32_t *tile, int32_t *split_k);

@@ -68,7 +68,7 @@ def test_conv_matches_cpu(ops, dev, case, tile):
     ref = _conv_ref(x, w, stride, pad)
     xn = ops.nchw_to_nhwc(x.to(dev))
     wp = ops.pack_conv_weight(w.to(dev))
-    for split in ([0, 1, 3] if tile in (0, 3) else [0]):
+    for split in ([0, 1, 3, -1] if tile in (0, 3) else [0, -1]):
         y = ops.conv2d_nhwc(xn, wp, stride=stride, pad=pad, tile=tile, split_k=split)
         got = ops.nhwc_to_nchw(y).cpu()
         tol = 3e-6 * math.sqrt(Cin * k * k) + 1e-5

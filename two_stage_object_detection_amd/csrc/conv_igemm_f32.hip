@@ -47,30 +47,35 @@ struct ConvParams {
     int act;
     float slope;
     int res_pitch, res_off;
-    int M, K, ksteps, split_k, ksteps_per_split, tiles_m, tiles_n;
+    int M, K, ksteps, tiles_m, tiles_n;
+    // schedule: workgroups [0, dp_tiles) each own one whole output tile; the remaining tiles are cut into
+    // `split` K-slices, one workgroup per (tile, slice), partial sums reduced by conv_reduce_kernel
+    int dp_tiles, split, ksteps_per_split;
+    unsigned out_bytes, res_bytes;
+    unsigned in_bytes, w_bytes;   // buffer-descriptor extents (hardware bounds check: out of range reads 0)
+    float neg_slope, act_hi;      // activation as min(max(v,0) + neg_slope*min(v,0), act_hi)
+    float inv_cin, inv_kw;        // reciprocals for the branch-free k -> (kh, kw, ci) split
 };
 
-__device__ __forceinline__ float apply_act(float v, int act, float slope) {
-    switch (act) {
-        case TSOD_ACT_PRELU: return v > 0.f ? v : v * slope;
-        case TSOD_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
-        case TSOD_ACT_RELU: return fmaxf(v, 0.f);
-        default: return v;
-    }
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0xFFFFFFF0u;  // byte offset beyond any descriptor extent -> the load returns zeros
+
+__device__ __forceinline__ float4 buffer_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-// channel index inside the (concatenated) Cin -> offset inside the input pixel
+// Branch-free activation: y = min(max(v,0) + neg_slope * min(v,0), hi) covers NONE (1, +inf), PRELU (a, +inf),
+// RELU (0, +inf) and RELU6 (0, 6) exactly (one of the two terms is always an exact zero).
+__device__ __forceinline__ float apply_act(float v, float neg_slope, float hi) {
+    return fminf(fmaxf(v, 0.f) + neg_slope * fminf(v, 0.f), hi);
+}
+
+// channel index inside the (concatenated) Cin -> offset inside the input pixel (select chain, no branches)
 __device__ __forceinline__ int seg_channel(const ConvParams &p, int ci) {
-    if (p.n_seg == 1) return p.seg_off[0] + ci;
-    int start = 0;
-#pragma unroll
-    for (int s = 0; s < TSOD_MAX_SEGMENTS; ++s) {
-        if (s < p.n_seg) {
-            if (ci < p.seg_end[s]) return p.seg_off[s] + (ci - start);
-            start = p.seg_end[s];
-        }
-    }
-    return p.seg_off[0];
+    int ch = p.seg_off[0] + ci;
+    for (int s = 1; s < p.n_seg; ++s) ch = ci >= p.seg_end[s - 1] ? p.seg_off[s] + (ci - p.seg_end[s - 1]) : ch;
+    return ch;
 }
 
 template <int BM, int BN, int MIN_WAVES>
@@ -85,22 +90,32 @@ __global__ void __launch_bounds__(256, MIN_WAVES) conv_igemm_kernel(const ConvPa
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // ---- XCD-aware workgroup id: blocks b, b+8, b+16.. share an XCD; give each XCD a contiguous run
-    const int nwg = gridDim.x;
-    const int q = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
-    const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (blockIdx.x >> 3);
-    const int tn_i = wgid % p.tiles_n;
-    const int t2 = wgid / p.tiles_n;
-    const int tm_i = t2 % p.tiles_m;
-    const int z = t2 / p.tiles_m;
+    // ---- workgroup -> work.  Whole-tile workgroups come first and are remapped so that each XCD (private
+    // L2; blocks b, b+8, ... share one) walks a contiguous run of tiles sharing activation rows.  K-slice
+    // workgroups keep the round-robin placement: they are dispatched last and spread over all XCDs.
+    int tile_id, z;
+    if ((int)blockIdx.x < p.dp_tiles) {
+        const int nwg = p.dp_tiles;
+        const int q = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+        tile_id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (blockIdx.x >> 3);
+        z = -1;
+    } else {
+        const int r = blockIdx.x - p.dp_tiles;
+        tile_id = p.dp_tiles + r / p.split;
+        z = r % p.split;
+    }
+    const int tn_i = tile_id % p.tiles_n;
+    const int tm_i = tile_id / p.tiles_n;
     const int m0 = tm_i * BM, n0 = tn_i * BN;
-    const int kt_begin = z * p.ksteps_per_split;
-    const int kt_end = min(p.ksteps, kt_begin + p.ksteps_per_split);
+    const int kt_begin = z < 0 ? 0 : z * p.ksteps_per_split;
+    const int kt_end = z < 0 ? p.ksteps : min(p.ksteps, kt_begin + p.ksteps_per_split);
 
-    // ---- per-thread staging geometry
+    // ---- per-thread staging geometry (all offsets are 32-bit BYTE offsets into buffer descriptors)
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, (short)0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, (short)0, (int)p.w_bytes, 0x00020000);
     const int c4 = (tid & 7) * 4;  // k offset of this thread's chunk inside the K-step
     const int r0 = tid >> 3;       // 0..31
-    long a_base[A_ROWS];
+    unsigned a_base[A_ROWS];
     int a_ih0[A_ROWS], a_iw0[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
@@ -112,53 +127,46 @@ __global__ void __launch_bounds__(256, MIN_WAVES) conv_igemm_kernel(const ConvPa
             const int img = t / p.OH;
             a_ih0[i] = oh * p.stride - p.pad_h;
             a_iw0[i] = ow * p.stride - p.pad_w;
-            a_base[i] = (((long)img * p.H + a_ih0[i]) * p.W + a_iw0[i]) * p.in_pitch;
+            // may wrap below zero for border rows; adding a valid tap's delta brings it back in range
+            a_base[i] = (unsigned)((((long)img * p.H + a_ih0[i]) * p.W + a_iw0[i]) * p.in_pitch) * 4u;
         } else {
             a_ih0[i] = INT_MIN / 2;
             a_iw0[i] = INT_MIN / 2;
             a_base[i] = 0;
         }
     }
-    long b_base[B_ROWS];
-    bool b_ok[B_ROWS];
+    unsigned b_base[B_ROWS];
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) {
         const int n = n0 + r0 + 32 * i;
-        b_ok[i] = n < p.Cout;
-        b_base[i] = (long)n * p.K;
+        b_base[i] = n < p.Cout ? (unsigned)n * (unsigned)p.K * 4u : kOOB;
     }
 
-    // running decomposition of this thread's k into (kh, kw, ci)
-    int k = kt_begin * kBK + c4;
-    int seg = k / p.Cin;
-    int ci = k - seg * p.Cin;
-    int kh = seg / p.KW;
-    int kw = seg - kh * p.KW;
+    int k = kt_begin * kBK + c4;  // this thread's k for the K-step being loaded
 
-    float4 ra[A_ROWS], rb[B_ROWS];
-    auto load_global = [&]() {
+    // Two register staging sets: the loads of K-step kt+2 are issued while step kt computes and are only
+    // written to LDS at the end of step kt+1, so a workgroup tolerates ~2 K-steps of memory latency (a lone
+    // workgroup per CU is otherwise bound by one L2/HBM round trip per K-step).
+    float4 ra0[A_ROWS], rb0[B_ROWS], ra1[A_ROWS], rb1[B_ROWS];
+    auto load_global = [&](float4(&ra)[A_ROWS], float4(&rb)[B_ROWS]) {
+        // k -> (filter tap, channel) without divisions or loops: exact for k < 2^21
+        const int seg = (int)(((float)k + 0.5f) * p.inv_cin);
+        const int ci = k - seg * p.Cin;
+        const int kh = (int)(((float)seg + 0.5f) * p.inv_kw);
+        const int kw = seg - kh * p.KW;
         const bool kin = k < p.K;
-        const long delta = ((long)kh * p.W + kw) * p.in_pitch + seg_channel(p, ci);
+        const unsigned delta = (unsigned)(((kh * p.W + kw) * p.in_pitch + seg_channel(p, ci)) * 4);
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
             const bool ok = kin && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            ra[i] = ok ? *reinterpret_cast<const float4 *>(p.in + a_base[i] + delta) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[i] = buffer_load4(rs_in, ok ? a_base[i] + delta : kOOB);
         }
 #pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) {
-            rb[i] = (kin && b_ok[i]) ? *reinterpret_cast<const float4 *>(p.w + b_base[i] + k)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        // advance to the next K-step
+        for (int i = 0; i < B_ROWS; ++i) rb[i] = buffer_load4(rs_w, (kin && b_base[i] != kOOB) ? b_base[i] + (unsigned)k * 4u : kOOB);
         k += kBK;
-        ci += kBK;
-        while (ci >= p.Cin) {
-            ci -= p.Cin;
-            if (++kw == p.KW) { kw = 0; ++kh; }
-        }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf, const float4(&ra)[A_ROWS], const float4(&rb)[B_ROWS]) {
         float *As = smem + buf * STAGE;
         float *Bs = As + BM * kLDK;
 #pragma unroll
@@ -177,90 +185,131 @@ __global__ void __launch_bounds__(256, MIN_WAVES) conv_igemm_kernel(const ConvPa
 
     const int frag_row = lane & 31;
     const int frag_k = 4 * (lane >> 5);
+    auto compute = [&](int buf) {
+        const float *As = smem + buf * STAGE + (wm * (BM / 2) + frag_row) * kLDK + frag_k;
+        const float *Bs = smem + buf * STAGE + BM * kLDK + (wn * (BN / 2) + frag_row) * kLDK + frag_k;
+#pragma unroll
+        for (int ks = 0; ks < kBK / 8; ++ks) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4 *>(As + i * 32 * kLDK + ks * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * kLDK + ks * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    };
 
-    if (kt_begin < kt_end) {
-        load_global();
-        store_lds(0);
+    const int nk = kt_end - kt_begin;
+    if (nk > 0) {
+        load_global(ra0, rb0);                       // step 0
+        if (nk > 1) load_global(ra1, rb1);           // step 1
+        store_lds(0, ra0, rb0);
         __syncthreads();
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
-            const int buf = (kt - kt_begin) & 1;
-            const bool more = kt + 1 < kt_end;
-            if (more) load_global();  // in flight while the MFMAs below run
-            const float *As = smem + buf * STAGE + (wm * (BM / 2) + frag_row) * kLDK + frag_k;
-            const float *Bs = smem + buf * STAGE + BM * kLDK + (wn * (BN / 2) + frag_row) * kLDK + frag_k;
-#pragma unroll
-            for (int ks = 0; ks < kBK / 8; ++ks) {
-                float4 fa[TM], fb[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4 *>(As + i * 32 * kLDK + ks * 8);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * kLDK + ks * 8);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                    }
-            }
-            if (more) store_lds(buf ^ 1);
+        for (int it = 0; it < nk; it += 2) {
+            // even step `it`: computes LDS buffer 0; set 0 is free -> prefetch step it+2; set 1 holds step it+1
+            if (it + 2 < nk) load_global(ra0, rb0);
+            compute(0);
+            if (it + 1 < nk) store_lds(1, ra1, rb1);
+            __syncthreads();
+            if (it + 1 >= nk) break;
+            // odd step it+1: computes LDS buffer 1; prefetch step it+3 into set 1; set 0 holds step it+2
+            if (it + 3 < nk) load_global(ra1, rb1);
+            compute(1);
+            if (it + 2 < nk) store_lds(0, ra0, rb0);
             __syncthreads();
         }
     }
 
-    // ---- epilogue.  acc[i][j][e]: column = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (m)
+    // ---- epilogue.  acc[i][j][e]: column = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (m).
+    // All global accesses go through buffer descriptors: rows / columns outside the problem get the
+    // out-of-range offset, so there is no per-element branch (loads return 0, stores are dropped), and the
+    // 16 residual loads of a 32x32 tile are all in flight before the first one is consumed.
     const int col_in = lane & 31;
     const int row_in = 4 * (lane >> 5);
-    if (p.split_k > 1) {
-        float *dst = p.partial + (long)z * p.M * p.Cout;
+    if (z >= 0) {
+        // K-slice: the whole BM x BN partial tile (zero rows / columns included) goes to its own slab
+        float *slab = p.partial + ((long)(tile_id - p.dp_tiles) * p.split + z) * (BM * BN);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 32 + col_in;
-            if (n >= p.Cout) continue;
+            const int cl = wn * (BN / 2) + j * 32 + col_in;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                const int rl = wm * (BM / 2) + i * 32 + row_in;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + row_in;
-                    if (m < p.M) dst[(long)m * p.Cout + n] = acc[i][j][e];
-                }
+                for (int e = 0; e < 16; ++e) slab[(rl + (e & 3) + 8 * (e >> 2)) * BN + cl] = acc[i][j][e];
+            }
         }
         return;
     }
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, (short)0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), (short)0,
+                                                                             (int)(p.res ? p.res_bytes : 0u), 0x00020000);
+    const bool has_res = p.res != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + col_in;
-        if (n >= p.Cout) continue;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        const float sh = p.shift ? p.shift[n] : 0.f;
+        const bool n_ok = n < p.Cout;
+        const float sc = (p.scale && n_ok) ? p.scale[n] : 1.f;
+        const float sh = (p.shift && n_ok) ? p.shift[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * (BM / 2) + i * 32 + row_in;
+            float r[16];
+            if (has_res) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + (e & 3) + 8 * (e >> 2);
+                    const unsigned off = (m < p.M && n_ok) ? ((unsigned)m * (unsigned)p.res_pitch + (unsigned)(p.res_off + n)) * 4u : kOOB;
+                    r[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, off, 0, 0));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) r[e] = 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + row_in;
-                if (m < p.M) {
-                    float v = acc[i][j][e] * sc + sh;
-                    if (p.res) v += p.res[(long)m * p.res_pitch + p.res_off + n];
-                    p.out[(long)m * p.out_pitch + p.out_off + n] = apply_act(v, p.act, p.slope);
-                }
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                const unsigned off = (m < p.M && n_ok) ? ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u : kOOB;
+                const float v = apply_act(acc[i][j][e] * sc + sh + r[e], p.neg_slope, p.act_hi);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, off, 0, 0);
             }
+        }
     }
 }
 
-// Deterministic split-K tail: sum the S partial slabs in slab order, then the same epilogue.
-__global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvParams p) {
-    const long total = (long)p.M * p.Cout;
-    const long slab = total;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int m = (int)(t / p.Cout);
-        const int n = (int)(t - (long)m * p.Cout);
-        float v = p.partial[t];
-        for (int s = 1; s < p.split_k; ++s) v += p.partial[(long)s * slab + t];
-        v = v * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
-        if (p.res) v += p.res[(long)m * p.res_pitch + p.res_off + n];
-        p.out[(long)m * p.out_pitch + p.out_off + n] = apply_act(v, p.act, p.slope);
+// Deterministic K-slice tail: one workgroup per sliced tile sums its `split` partial tiles in slice order
+// (fixed summation order -> bit-reproducible), then applies the same epilogue.
+__global__ void __launch_bounds__(256) conv_reduce_kernel(const ConvParams p, int BM, int BN) {
+    const int tile_id = p.dp_tiles + blockIdx.x;
+    const int m0 = (tile_id / p.tiles_n) * BM, n0 = (tile_id % p.tiles_n) * BN;
+    const float4 *slabs = reinterpret_cast<const float4 *>(p.partial + (long)blockIdx.x * p.split * BM * BN);
+    const int quads = BM * BN / 4, qpr = BN / 4;
+    for (int idx = threadIdx.x; idx < quads; idx += blockDim.x) {
+        float4 v = slabs[idx];
+        for (int s = 1; s < p.split; ++s) {
+            const float4 t = slabs[(long)s * quads + idx];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const int m = m0 + idx / qpr;
+        const int nb = n0 + (idx % qpr) * 4;
+        if (m >= p.M) continue;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int n = nb + c;
+            if (n >= p.Cout) continue;
+            float o = vv[c] * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+            if (p.res) o += p.res[(long)m * p.res_pitch + p.res_off + n];
+            p.out[(long)m * p.out_pitch + p.out_off + n] = apply_act(o, p.neg_slope, p.act_hi);
+        }
     }
 }
 
@@ -302,7 +351,7 @@ int validate(const tsod_conv2d_desc *d) {
     TSOD_REQUIRE((d->OH - 1) * d->stride - d->pad_h < d->H && (d->OW - 1) * d->stride - d->pad_w < d->W,
                  TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->act >= TSOD_ACT_NONE && d->act <= TSOD_ACT_RELU, TSOD_ERR_INVALID_ARG);
-    TSOD_REQUIRE(d->tile >= 0 && d->tile < TSOD_TILE_COUNT && d->split_k >= 0 && d->split_k <= 64, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(d->tile >= 0 && d->tile < TSOD_TILE_COUNT && d->split_k >= -1 && d->split_k <= 64, TSOD_ERR_INVALID_ARG);
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
     TSOD_REQUIRE(M < (int64_t)INT_MAX, TSOD_ERR_UNSUPPORTED);
     return TSOD_OK;
@@ -329,38 +378,83 @@ int cu_count() {
     return g_cu_count;
 }
 
-// Cost model, in CU-cycles of the most loaded CU: workgroups are dealt round-robin over the CUs and
-// co-resident workgroups share the CU's matrix pipes, so a CU's time is (its workgroups) x (K-steps x
-// BM*BN/4 MFMA cycles + a fixed prologue/epilogue), plus the slab round trip when K is split.
-void resolve(const tsod_conv2d_desc *d, int *tile_out, int *split_out) {
+// Workgroups that fit on one CU at a time (LDS-bound: 2 stages of (BM+BN) x 36 floats out of 160 KiB).
+int residency(int tile) { return tile == TSOD_TILE_64x64 ? 4 : 2; }
+
+struct Sched {
+    int tile, bm, bn, tiles_m, tiles_n, tiles, dp_tiles, rem_tiles, split, ksteps_per_split, grid;
+    size_t ws_bytes;
+    double cost;
+};
+
+// desc.split_k:  1 = every tile whole (no K split);  S > 1 = every tile cut into S K-slices;
+//               -1 = hybrid: as many full chip-waves of whole tiles as fit, the left-over tiles cut into
+//                    K-slices so that the last wave also fills the chip;  0 = let the cost model choose.
+Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
+    Sched s;
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
     const int K = d->KH * d->KW * desc_cin(d);
     const int ksteps = (K + kBK - 1) / kBK;
-    const int cus = cu_count();
-    double best = 1e300;
-    int best_tile = TSOD_TILE_128x128, best_split = 1;
-    for (int t = 1; t < TSOD_TILE_COUNT; ++t) {
-        if (d->tile != TSOD_TILE_AUTO && d->tile != t) continue;
-        const int bm = kTiles[t].bm, bn = kTiles[t].bn;
-        const int64_t tiles = tsod_cdiv(M, bm) * tsod_cdiv(d->Cout, bn);
-        for (int s = 1; s <= 32; s = (d->split_k != 0 ? 64 : s * 2)) {
-            if (d->split_k != 0) s = d->split_k < ksteps ? d->split_k : ksteps;  // explicit request: honour it
-            else if (s > 1 && ksteps / s < 2) continue;
-            const int per = (ksteps + s - 1) / s;
-            const int64_t wgs = tiles * s;
-            const double per_wg = (double)per * bm * bn / 4.0 * kTiles[t].cost + 2500.0 + (double)bm * bn / 8.0;
-            double cost = (double)tsod_cdiv(wgs, cus) * per_wg;
-            if (s > 1) cost += 4000.0 + (double)(s + 1) * M * d->Cout * 4.0 / 2000.0;  // ~2 KB / cycle chip-wide
-            if (cost < best) { best = cost; best_tile = t; best_split = s; }
+    s.tile = tile; s.bm = kTiles[tile].bm; s.bn = kTiles[tile].bn;
+    s.tiles_m = (int)tsod_cdiv(M, s.bm); s.tiles_n = (int)tsod_cdiv(d->Cout, s.bn);
+    s.tiles = s.tiles_m * s.tiles_n;
+    const int slots = cu_count() * residency(tile);
+    int split = 1, dp = s.tiles;
+    if (mode > 1) {
+        split = mode < ksteps ? mode : ksteps;
+        dp = 0;
+    } else if (mode == -1) {
+        const int full = s.tiles / slots * slots;
+        const int rem = s.tiles - full;
+        if (rem > 0) {
+            split = slots / rem;
+            if (split > ksteps / 2) split = ksteps / 2;      // at least 2 K-steps per slice
+            if (split < 1) split = 1;
+            if (split > 1) dp = full;
         }
     }
-    *tile_out = best_tile;
-    *split_out = best_split;
+    int kps = (ksteps + split - 1) / split;
+    split = (ksteps + kps - 1) / kps;                         // no empty slices
+    if (split <= 1) { split = 1; dp = s.tiles; kps = ksteps; }
+    s.split = split; s.ksteps_per_split = kps; s.dp_tiles = dp; s.rem_tiles = s.tiles - dp;
+    s.grid = dp + s.rem_tiles * split;
+    s.ws_bytes = (size_t)s.rem_tiles * split * s.bm * s.bn * sizeof(float);
+    // cost, in cycles of the most loaded CU: co-resident workgroups share the CU's matrix pipes, so a wave of
+    // workgroups costs (workgroups per CU) x (K-steps x BM*BN/4 MFMA cycles + fixed prologue/epilogue)
+    const double step = (double)s.bm * s.bn / 4.0 * kTiles[tile].cost;
+    const double fixed = 3000.0 + (double)s.bm * s.bn / 8.0;
+    const int cus = cu_count();
+    double c = (double)tsod_cdiv(dp, cus) * (ksteps * step + fixed);
+    if (s.rem_tiles > 0)
+        c += (double)tsod_cdiv((int64_t)s.rem_tiles * split, cus) * (kps * step + fixed) + 5000.0 +
+             (double)s.rem_tiles * (split + 1) * s.bm * s.bn * 4.0 / 2000.0;
+    s.cost = c;
+    return s;
+}
+
+Sched resolve(const tsod_conv2d_desc *d) {
+    Sched best;
+    best.cost = 1e300;
+    for (int t = 1; t < TSOD_TILE_COUNT; ++t) {
+        if (d->tile != TSOD_TILE_AUTO && d->tile != t) continue;
+        if (d->split_k != 0) {
+            const Sched s = make_sched(d, t, d->split_k);
+            if (s.cost < best.cost) best = s;
+            continue;
+        }
+        const int K = d->KH * d->KW * desc_cin(d);
+        const int ksteps = (K + kBK - 1) / kBK;
+        for (int mode : {1, -1, 2, 4, 8, 16}) {
+            if (mode > 1 && ksteps / mode < 2) continue;
+            const Sched s = make_sched(d, t, mode);
+            if (s.cost < best.cost) best = s;
+        }
+    }
+    return best;
 }
 
 template <int BM, int BN, int MW>
-void launch_tile(const ConvParams &p, hipStream_t s) {
-    const int grid = p.tiles_m * p.tiles_n * p.split_k;
+void launch_tile(const ConvParams &p, int grid, hipStream_t s) {
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MW>), dim3(grid), dim3(256), 0, s, p);
 }
 
@@ -370,19 +464,15 @@ extern "C" int tsod_conv2d_resolve(const tsod_conv2d_desc *d, int32_t *tile, int
     const int rc = validate(d);
     if (rc != TSOD_OK) return rc;
     TSOD_REQUIRE(tile && split_k, TSOD_ERR_INVALID_ARG);
-    int t, s;
-    resolve(d, &t, &s);
-    *tile = t;
-    *split_k = s;
+    const Sched s = resolve(d);
+    *tile = s.tile;
+    *split_k = s.rem_tiles == 0 ? 1 : (s.dp_tiles == 0 ? s.split : -1);
     return TSOD_OK;
 }
 
 extern "C" size_t tsod_conv2d_workspace_bytes(const tsod_conv2d_desc *d) {
     if (validate(d) != TSOD_OK) return 0;
-    int t, s;
-    resolve(d, &t, &s);
-    if (s <= 1) return 0;
-    return (size_t)s * (size_t)d->N * d->OH * d->OW * (size_t)d->Cout * sizeof(float);
+    return resolve(d).ws_bytes;
 }
 
 extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const float *w_packed, const float *scale,
@@ -412,30 +502,37 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
     p.M = d->N * d->OH * d->OW;
     p.K = d->KH * d->KW * p.Cin;
     p.ksteps = (p.K + kBK - 1) / kBK;
-    int tile, split;
-    resolve(d, &tile, &split);
-    if (split > p.ksteps) split = p.ksteps;
-    p.split_k = split;
-    p.ksteps_per_split = (p.ksteps + split - 1) / split;
-    p.split_k = (p.ksteps + p.ksteps_per_split - 1) / p.ksteps_per_split;  // no empty slabs
-    p.tiles_m = (int)tsod_cdiv(p.M, kTiles[tile].bm);
-    p.tiles_n = (int)tsod_cdiv(p.Cout, kTiles[tile].bn);
-    if (p.split_k > 1) {
-        const size_t need = (size_t)p.split_k * (size_t)p.M * (size_t)p.Cout * sizeof(float);
-        TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= need, TSOD_ERR_WORKSPACE);
+    {
+        const uint64_t in_bytes = (uint64_t)d->N * d->H * d->W * d->in_pitch * sizeof(float);
+        const uint64_t w_bytes = (uint64_t)d->Cout * p.K * sizeof(float);
+        const uint64_t out_bytes = (uint64_t)p.M * d->out_pitch * sizeof(float);
+        const uint64_t res_bytes = residual ? (uint64_t)p.M * d->res_pitch * sizeof(float) : 0;
+        // 32-bit buffer offsets: one activation tensor must stay below 4 GiB (shard the batch otherwise)
+        TSOD_REQUIRE(in_bytes < 0xFFFFFFF0ull && w_bytes < 0xFFFFFFF0ull && out_bytes < 0xFFFFFFF0ull &&
+                         res_bytes < 0xFFFFFFF0ull && p.K < (1 << 21),
+                     TSOD_ERR_UNSUPPORTED);
+        p.in_bytes = (unsigned)in_bytes;
+        p.w_bytes = (unsigned)w_bytes;
+        p.out_bytes = (unsigned)out_bytes;
+        p.res_bytes = (unsigned)res_bytes;
+        p.neg_slope = d->act == TSOD_ACT_NONE ? 1.f : (d->act == TSOD_ACT_PRELU ? d->slope : 0.f);
+        p.act_hi = d->act == TSOD_ACT_RELU6 ? 6.f : __builtin_huge_valf();
+        p.inv_cin = 1.0f / (float)p.Cin;
+        p.inv_kw = 1.0f / (float)d->KW;
     }
+    const Sched sc = resolve(d);
+    p.tiles_m = sc.tiles_m; p.tiles_n = sc.tiles_n;
+    p.dp_tiles = sc.dp_tiles; p.split = sc.split; p.ksteps_per_split = sc.ksteps_per_split;
+    if (sc.rem_tiles > 0) TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= sc.ws_bytes, TSOD_ERR_WORKSPACE);
     hipStream_t s = tsod_stream(stream);
-    switch (tile) {
-        case TSOD_TILE_128x128: launch_tile<128, 128, 2>(p, s); break;
-        case TSOD_TILE_128x64: launch_tile<128, 64, 2>(p, s); break;
-        case TSOD_TILE_64x128: launch_tile<64, 128, 2>(p, s); break;
-        default: launch_tile<64, 64, 4>(p, s); break;
+    switch (sc.tile) {
+        case TSOD_TILE_128x128: launch_tile<128, 128, 2>(p, sc.grid, s); break;
+        case TSOD_TILE_128x64: launch_tile<128, 64, 2>(p, sc.grid, s); break;
+        case TSOD_TILE_64x128: launch_tile<64, 128, 2>(p, sc.grid, s); break;
+        default: launch_tile<64, 64, 4>(p, sc.grid, s); break;
     }
-    if (p.split_k > 1) {
-        const long total = (long)p.M * p.Cout;
-        const int blocks = (int)(tsod_cdiv(total, 256) < 2048 ? tsod_cdiv(total, 256) : 2048);
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
-    }
+    if (sc.rem_tiles > 0)
+        hipLaunchKernelGGL(conv_reduce_kernel, dim3(sc.rem_tiles), dim3(256), 0, s, p, sc.bm, sc.bn);
     return tsod_launch_status();
 }
 
@@ -468,4 +565,17 @@ extern "C" int tsod_pack_conv_weight_f32(const float *w_oihw, int32_t Cout, int3
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), w_oihw, Cout, Cin_src, KH,
                        KW_src, Cin, KW, w_packed);
     return tsod_launch_status();
+}
+
+// Diagnostic (not part of the public ABI): occupancy the runtime grants each conv tile kernel.
+extern "C" int tsod_debug_conv_occupancy(int tile) {
+    int n = -1;
+    hipError_t e;
+    switch (tile) {
+        case TSOD_TILE_128x128: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<128, 128, 2>, 256, 0); break;
+        case TSOD_TILE_128x64: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<128, 64, 2>, 256, 0); break;
+        case TSOD_TILE_64x128: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<64, 128, 2>, 256, 0); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<64, 64, 4>, 256, 0); break;
+    }
+    return e == hipSuccess ? n : -(int)e;
 }

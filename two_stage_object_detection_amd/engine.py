@@ -197,8 +197,8 @@ class Plan:
             M = d.N * d.OH * d.OW
             cands = []
             for tile in (1, 2, 3, 4):
-                for split in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
-                    if split > 1 and (ksteps // split < 2 or split * M * d.Cout * 4 > big.numel()):
+                for split in (1, -1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+                    if split > 1 and (ksteps // split < 2 or split * (M + 128) * (d.Cout + 128) * 4 > big.numel()):
                         continue
                     cands.append((tile, split))
             best = None
@@ -221,7 +221,7 @@ class Plan:
             d.tile, d.split_k = best[1], best[2]
             results.append((st.name, best[0], best[1], best[2], st.flops))
             if verbose:
-                print(f"  {st.name:34s} {TILE_NAMES[best[1]]:8s} split {best[2]:2d}  {best[0] * 1e3:8.1f} us "
+                print(f"  {st.name:34s} {TILE_NAMES[best[1]]:8s} split {best[2]:3d}  {best[0] * 1e3:8.1f} us "
                       f"{st.flops / best[0] / 1e9:7.1f} TF/s")
         del big
         self.finalize()
