@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32,
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libtsod.so")
+LIB_PATH = os.environ.get("TSOD_LIB") or os.path.join(_PKG_DIR, "libtsod.so")   # TSOD_LIB: alternate build (experiments)
 
 TSOD_MAX_SEGMENTS = 16
 ACT_NONE, ACT_PRELU, ACT_RELU6, ACT_RELU = 0, 1, 2, 3

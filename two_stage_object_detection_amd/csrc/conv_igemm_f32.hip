@@ -185,26 +185,44 @@ __global__ void __launch_bounds__(256, MIN_WAVES) conv_igemm_kernel(const ConvPa
 
     const int frag_row = lane & 31;
     const int frag_k = 4 * (lane >> 5);
-    auto compute = [&](int buf) {
-        const float *As = smem + buf * STAGE + (wm * (BM / 2) + frag_row) * kLDK + frag_k;
-        const float *Bs = smem + buf * STAGE + BM * kLDK + (wn * (BN / 2) + frag_row) * kLDK + frag_k;
+    const int a_frag_off = (wm * (BM / 2) + frag_row) * kLDK + frag_k;
+    const int b_frag_off = BM * kLDK + (wn * (BN / 2) + frag_row) * kLDK + frag_k;
+
+    // One K-step.  Instruction order is chosen so that every latency sits under matrix-core time:
+    //   LDS fragment reads of sub-step ks+1 are issued before the MFMAs of sub-step ks (register double buffer),
+    //   the global loads of step kt+2 (address VALU + buffer_load) are issued while the first fragments fly,
+    //   the LDS writes of step kt+1 are issued behind the first MFMA group and complete under the rest.
+    auto kstep = [&](int buf, bool do_load, float4(&lra)[A_ROWS], float4(&lrb)[B_ROWS], bool do_store,
+                     const float4(&sra)[A_ROWS], const float4(&srb)[B_ROWS]) {
+        const float *As = smem + buf * STAGE + a_frag_off;
+        const float *Bs = smem + buf * STAGE + b_frag_off;
+        float4 fa[2][TM], fb[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const float4 *>(As + i * 32 * kLDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * kLDK);
+        if (do_load) load_global(lra, lrb);
 #pragma unroll
         for (int ks = 0; ks < kBK / 8; ++ks) {
-            float4 fa[TM], fb[TN];
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < kBK / 8) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4 *>(As + i * 32 * kLDK + ks * 8);
+                for (int i = 0; i < TM; ++i) fa[nxt][i] = *reinterpret_cast<const float4 *>(As + i * 32 * kLDK + (ks + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * kLDK + ks * 8);
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * kLDK + (ks + 1) * 8);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
                 }
+            if (ks == 0 && do_store) store_lds(buf ^ 1, sra, srb);
         }
+        __syncthreads();
     };
 
     const int nk = kt_end - kt_begin;
@@ -214,17 +232,11 @@ __global__ void __launch_bounds__(256, MIN_WAVES) conv_igemm_kernel(const ConvPa
         store_lds(0, ra0, rb0);
         __syncthreads();
         for (int it = 0; it < nk; it += 2) {
-            // even step `it`: computes LDS buffer 0; set 0 is free -> prefetch step it+2; set 1 holds step it+1
-            if (it + 2 < nk) load_global(ra0, rb0);
-            compute(0);
-            if (it + 1 < nk) store_lds(1, ra1, rb1);
-            __syncthreads();
+            // even step: LDS buffer 0; set 0 is free -> prefetch step it+2 into it; set 1 (step it+1) -> LDS buffer 1
+            kstep(0, it + 2 < nk, ra0, rb0, it + 1 < nk, ra1, rb1);
             if (it + 1 >= nk) break;
-            // odd step it+1: computes LDS buffer 1; prefetch step it+3 into set 1; set 0 holds step it+2
-            if (it + 3 < nk) load_global(ra1, rb1);
-            compute(1);
-            if (it + 2 < nk) store_lds(0, ra0, rb0);
-            __syncthreads();
+            // odd step: LDS buffer 1; prefetch step it+3 into set 1; set 0 (step it+2) -> LDS buffer 0
+            kstep(1, it + 3 < nk, ra1, rb1, it + 2 < nk, ra0, rb0);
         }
     }
 
@@ -285,30 +297,55 @@ __global__ void __launch_bounds__(256, MIN_WAVES) conv_igemm_kernel(const ConvPa
     }
 }
 
-// Deterministic K-slice tail: one workgroup per sliced tile sums its `split` partial tiles in slice order
-// (fixed summation order -> bit-reproducible), then applies the same epilogue.
-__global__ void __launch_bounds__(256) conv_reduce_kernel(const ConvParams p, int BM, int BN) {
-    const int tile_id = p.dp_tiles + blockIdx.x;
-    const int m0 = (tile_id / p.tiles_n) * BM, n0 = (tile_id % p.tiles_n) * BN;
-    const float4 *slabs = reinterpret_cast<const float4 *>(p.partial + (long)blockIdx.x * p.split * BM * BN);
+// Deterministic K-slice tail: every thread owns one float4 (4 consecutive output channels of one pixel) of one
+// sliced tile, sums its `split` partial values in slice order (fixed order -> bit-reproducible; the loads of a
+// batch of 8 slices are all in flight before the first add) and applies the epilogue.
+__global__ void __launch_bounds__(256) conv_reduce_kernel(const ConvParams p, int BM, int BN, int rem_tiles) {
     const int quads = BM * BN / 4, qpr = BN / 4;
-    for (int idx = threadIdx.x; idx < quads; idx += blockDim.x) {
-        float4 v = slabs[idx];
-        for (int s = 1; s < p.split; ++s) {
-            const float4 t = slabs[(long)s * quads + idx];
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
-        const int m = m0 + idx / qpr;
-        const int nb = n0 + (idx % qpr) * 4;
-        if (m >= p.M) continue;
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    const long total = (long)rem_tiles * quads;
+    const bool vec_ok = ((p.out_pitch | p.out_off) & 3) == 0 && (!p.res || ((p.res_pitch | p.res_off) & 3) == 0);
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int rt = (int)(t / quads);
+        const int idx = (int)(t - (long)rt * quads);
+        const float4 *slabs = reinterpret_cast<const float4 *>(p.partial) + (long)rt * p.split * quads + idx;
+        float4 v = slabs[0];
+        int s = 1;
+        for (; s + 8 <= p.split; s += 8) {
+            float4 q[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int n = nb + c;
-            if (n >= p.Cout) continue;
-            float o = vv[c] * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
-            if (p.res) o += p.res[(long)m * p.res_pitch + p.res_off + n];
-            p.out[(long)m * p.out_pitch + p.out_off + n] = apply_act(o, p.neg_slope, p.act_hi);
+            for (int u = 0; u < 8; ++u) q[u] = slabs[(long)(s + u) * quads];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v.x += q[u].x; v.y += q[u].y; v.z += q[u].z; v.w += q[u].w; }
+        }
+        for (; s < p.split; ++s) {
+            const float4 q = slabs[(long)s * quads];
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        const int tile_id = p.dp_tiles + rt;
+        const int m = (tile_id / p.tiles_n) * BM + idx / qpr;
+        const int nb = (tile_id % p.tiles_n) * BN + (idx % qpr) * 4;
+        if (m >= p.M || nb >= p.Cout) continue;
+        float vv[4] = {v.x, v.y, v.z, v.w};
+        if (nb + 3 < p.Cout && vec_ok) {
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f), rs = sh;
+            if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + nb);
+            if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + nb);
+            if (p.res) rs = *reinterpret_cast<const float4 *>(p.res + (long)m * p.res_pitch + p.res_off + nb);
+            float4 o;
+            o.x = apply_act(vv[0] * sc.x + sh.x + rs.x, p.neg_slope, p.act_hi);
+            o.y = apply_act(vv[1] * sc.y + sh.y + rs.y, p.neg_slope, p.act_hi);
+            o.z = apply_act(vv[2] * sc.z + sh.z + rs.z, p.neg_slope, p.act_hi);
+            o.w = apply_act(vv[3] * sc.w + sh.w + rs.w, p.neg_slope, p.act_hi);
+            *reinterpret_cast<float4 *>(p.out + (long)m * p.out_pitch + p.out_off + nb) = o;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int n = nb + c;
+                if (n >= p.Cout) continue;
+                float o = vv[c] * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+                if (p.res) o += p.res[(long)m * p.res_pitch + p.res_off + n];
+                p.out[(long)m * p.out_pitch + p.out_off + n] = apply_act(o, p.neg_slope, p.act_hi);
+            }
         }
     }
 }
@@ -532,7 +569,11 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
         default: launch_tile<64, 64, 4>(p, sc.grid, s); break;
     }
     if (sc.rem_tiles > 0)
-        hipLaunchKernelGGL(conv_reduce_kernel, dim3(sc.rem_tiles), dim3(256), 0, s, p, sc.bm, sc.bn);
+    {
+        const long quads = (long)sc.rem_tiles * sc.bm * sc.bn / 4;
+        const int blocks = (int)(tsod_cdiv(quads, 256) < 4096 ? tsod_cdiv(quads, 256) : 4096);
+        hipLaunchKernelGGL(conv_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, sc.bm, sc.bn, sc.rem_tiles);
+    }
     return tsod_launch_status();
 }
 
