@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--num-classes", type=int, default=80)
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--tiles-file", default=None, help="JSON cache of autotuned (tile, split) choices: loaded if present, "
+                                                       "else written after autotuning (keeps profiler runs free of tuning launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--verbose", action="store_true")
@@ -116,8 +118,12 @@ def main():
         model(x)                                                       # builds the plan
         torch.cuda.synchronize()
         plan = model.extractor._plan_for(x)
-        if not args.no_autotune:
-            res = plan.autotune(verbose=args.verbose and rank == 0)
+        if args.tiles_file and os.path.exists(args.tiles_file):
+            plan.import_tiles(json.load(open(args.tiles_file)))
+        elif not args.no_autotune:
+            plan.autotune(verbose=args.verbose and rank == 0)
+            if args.tiles_file and rank == 0:
+                json.dump(plan.export_tiles(), open(args.tiles_file, "w"))
         conv_ms = conv_event_times(plan)
         conv_flops = sum(st.flops for st in plan.conv_steps)
         if args.no_graph:

@@ -58,8 +58,9 @@ int tsod_device_cu_count(void);
  *   m = (img, oh, ow);  k = (kh, kw, ci) over the input SEGMENTS (see below);  n = output channel.
  * ---------------------------------------------------------------------------------------- */
 enum { TSOD_ACT_NONE = 0, TSOD_ACT_PRELU = 1, TSOD_ACT_RELU6 = 2, TSOD_ACT_RELU = 3 };
+/* workgroup tile (rows x output channels); _W8 = 8 waves (512 threads) instead of 4 */
 enum { TSOD_TILE_AUTO = 0, TSOD_TILE_128x128 = 1, TSOD_TILE_128x64 = 2, TSOD_TILE_64x64 = 3, TSOD_TILE_64x128 = 4,
-       TSOD_TILE_COUNT = 5 };
+       TSOD_TILE_128x128_W8 = 5, TSOD_TILE_128x64_W8 = 6, TSOD_TILE_256x128_W8 = 7, TSOD_TILE_COUNT = 8 };
 #define TSOD_MAX_SEGMENTS 16
 
 typedef struct tsod_conv2d_desc {
@@ -92,7 +93,8 @@ typedef struct tsod_conv2d_desc {
 int tsod_pack_conv_weight_f32(const float *w_oihw, int32_t Cout, int32_t Cin_src, int32_t KH, int32_t KW_src,
                               int32_t Cin, int32_t KW, float *w_packed, tsod_stream_t stream);
 
-/* Bytes of workspace tsod_conv2d_f32 needs for this descriptor (0 unless some tile is K-sliced). */
+/* Bytes of workspace tsod_conv2d_f32 needs for this descriptor (0 unless some tile is K-sliced).
+ * Workspace contract: 16-byte aligned, private to one stream at a time. */
 size_t tsod_conv2d_workspace_bytes(const tsod_conv2d_desc *d);
 /* Resolve TSOD_TILE_AUTO / split_k == 0 to the concrete choice the heuristic makes. */
 int tsod_conv2d_resolve(const tsod_conv2d_desc *d, int32_t *tile, int32_t *split_k);

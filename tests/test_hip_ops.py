@@ -59,7 +59,7 @@ def _conv_ref(x, w, stride, pad):
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_conv_matches_cpu(ops, dev, case, tile):
     N, H, W, Cin, Cout, k, stride, pad = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
@@ -73,6 +73,31 @@ def test_conv_matches_cpu(ops, dev, case, tile):
         got = ops.nhwc_to_nchw(y).cpu()
         tol = 3e-6 * math.sqrt(Cin * k * k) + 1e-5
         assert (got - ref).abs().max().item() <= tol, (case, tile, split)
+
+
+def test_conv_kslice_reduce_is_deterministic_under_load(ops, dev):
+    """K-sliced tiles: partial slabs written by the slice workgroups, summed in slice order by
+    conv_reduce_kernel.  Hundreds of back-to-back launches of several slice configurations, each compared
+    word for word with its first result (fixed summation order => bit-reproducible) and against the CPU.
+    Slabs are re-used across launches, so a stale (previous-launch) read would show up as a mismatch."""
+    g = torch.Generator().manual_seed(21)
+    for (H, W, Cin, Cout, k) in ((25, 42, 512, 512, 3), (50, 84, 256, 256, 3), (13, 17, 1024, 96, 1)):
+        x = torch.randn(1, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+        ref = _conv_ref(x, w, 1, k // 2)
+        xn, wp = ops.nchw_to_nhwc(x.to(dev)), ops.pack_conv_weight(w.to(dev))
+        noise = torch.randn(64 << 20, device=dev)                 # evicts L2 between some launches
+        for tile, split in ((3, 8), (3, -1), (1, 4), (6, 16), (4, -1)):
+            first = None
+            for it in range(60):
+                y = ops.conv2d_nhwc(xn, wp, pad=k // 2, tile=tile, split_k=split)
+                if it % 7 == 3:
+                    noise.mul_(1.0001)
+                if first is None:
+                    first = y.clone()
+                    assert (ops.nhwc_to_nchw(y).cpu() - ref).abs().max().item() <= 3e-6 * math.sqrt(Cin * k * k) + 1e-5
+                else:
+                    assert torch.equal(y, first), (H, W, Cin, Cout, k, tile, split, it)
 
 
 def test_conv_epilogue_bn_residual_prelu(ops, dev):

@@ -78,17 +78,22 @@ __device__ __forceinline__ int seg_channel(const ConvParams &p, int ci) {
     return ch;
 }
 
-template <int BM, int BN, int MIN_WAVES>
-__global__ void __launch_bounds__(256, MIN_WAVES) conv_igemm_kernel(const ConvParams p) {
-    constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 MFMA tiles per wave in m / n
-    constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;  // rows each thread stages per K-step
+// BM x BN workgroup tile, WM x WN per-wave tile: (BM/WM) x (BN/WN) waves of 64 lanes.
+template <int BM, int BN, int WM, int WN, int MIN_WAVES>
+__global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_igemm_kernel(const ConvParams p) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int THREADS = 64 * (BM / WM) * WAVES_N;
+    constexpr int RPP = THREADS / 8;                   // rows staged per pass (8 threads cover one 128-byte row)
+    constexpr int TM = WM / 32, TN = WN / 32;          // 32x32 MFMA tiles per wave in m / n
+    constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;  // rows each thread stages per K-step
     constexpr int STAGE = (BM + BN) * kLDK;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
     __shared__ __align__(16) float smem[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     // ---- workgroup -> work.  Whole-tile workgroups come first and are remapped so that each XCD (private
     // L2; blocks b, b+8, ... share one) walks a contiguous run of tiles sharing activation rows.  K-slice
@@ -114,12 +119,12 @@ __global__ void __launch_bounds__(256, MIN_WAVES) conv_igemm_kernel(const ConvPa
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, (short)0, (int)p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, (short)0, (int)p.w_bytes, 0x00020000);
     const int c4 = (tid & 7) * 4;  // k offset of this thread's chunk inside the K-step
-    const int r0 = tid >> 3;       // 0..31
+    const int r0 = tid >> 3;       // 0..RPP-1
     unsigned a_base[A_ROWS];
     int a_ih0[A_ROWS], a_iw0[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-        const int m = m0 + r0 + 32 * i;
+        const int m = m0 + r0 + RPP * i;
         if (m < p.M) {
             const int ow = m % p.OW;
             const int t = m / p.OW;
@@ -138,7 +143,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) conv_igemm_kernel(const ConvPa
     unsigned b_base[B_ROWS];
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) {
-        const int n = n0 + r0 + 32 * i;
+        const int n = n0 + r0 + RPP * i;
         b_base[i] = n < p.Cout ? (unsigned)n * (unsigned)p.K * 4u : kOOB;
     }
 
@@ -170,9 +175,9 @@ __global__ void __launch_bounds__(256, MIN_WAVES) conv_igemm_kernel(const ConvPa
         float *As = smem + buf * STAGE;
         float *Bs = As + BM * kLDK;
 #pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<float4 *>(As + (r0 + 32 * i) * kLDK + c4) = ra[i];
+        for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<float4 *>(As + (r0 + RPP * i) * kLDK + c4) = ra[i];
 #pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<float4 *>(Bs + (r0 + 32 * i) * kLDK + c4) = rb[i];
+        for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<float4 *>(Bs + (r0 + RPP * i) * kLDK + c4) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -185,8 +190,8 @@ __global__ void __launch_bounds__(256, MIN_WAVES) conv_igemm_kernel(const ConvPa
 
     const int frag_row = lane & 31;
     const int frag_k = 4 * (lane >> 5);
-    const int a_frag_off = (wm * (BM / 2) + frag_row) * kLDK + frag_k;
-    const int b_frag_off = BM * kLDK + (wn * (BN / 2) + frag_row) * kLDK + frag_k;
+    const int a_frag_off = (wm * WM + frag_row) * kLDK + frag_k;
+    const int b_frag_off = BM * kLDK + (wn * WN + frag_row) * kLDK + frag_k;
 
     // One K-step.  Instruction order is chosen so that every latency sits under matrix-core time:
     //   LDS fragment reads of sub-step ks+1 are issued before the MFMAs of sub-step ks (register double buffer),
@@ -251,10 +256,10 @@ __global__ void __launch_bounds__(256, MIN_WAVES) conv_igemm_kernel(const ConvPa
         float *slab = p.partial + ((long)(tile_id - p.dp_tiles) * p.split + z) * (BM * BN);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int cl = wn * (BN / 2) + j * 32 + col_in;
+            const int cl = wn * WN + j * 32 + col_in;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int rl = wm * (BM / 2) + i * 32 + row_in;
+                const int rl = wm * WM + i * 32 + row_in;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) slab[(rl + (e & 3) + 8 * (e >> 2)) * BN + cl] = acc[i][j][e];
             }
@@ -267,13 +272,13 @@ __global__ void __launch_bounds__(256, MIN_WAVES) conv_igemm_kernel(const ConvPa
     const bool has_res = p.res != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + col_in;
+        const int n = n0 + wn * WN + j * 32 + col_in;
         const bool n_ok = n < p.Cout;
         const float sc = (p.scale && n_ok) ? p.scale[n] : 1.f;
         const float sh = (p.shift && n_ok) ? p.shift[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * (BM / 2) + i * 32 + row_in;
+            const int mb = m0 + wm * WM + i * 32 + row_in;
             float r[16];
             if (has_res) {
 #pragma unroll
@@ -368,9 +373,10 @@ pack_weight_kernel(const float *__restrict__ w, int Cout, int Cin_src, int KH, i
     }
 }
 
-struct TileInfo { int bm, bn; float cost; };
+struct TileInfo { int bm, bn, threads, resident; float cost; };   // resident = workgroups per CU (LDS-bound)
 const TileInfo kTiles[TSOD_TILE_COUNT] = {
-    {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 1.06f}, {64, 64, 1.15f}, {64, 128, 1.06f}};
+    {0, 0, 0, 0, 0.f},          {128, 128, 256, 2, 1.00f}, {128, 64, 256, 2, 1.06f}, {64, 64, 256, 4, 1.15f},
+    {64, 128, 256, 2, 1.06f},   {128, 128, 512, 2, 1.00f}, {128, 64, 512, 2, 1.06f}, {256, 128, 512, 1, 0.98f}};
 
 int validate(const tsod_conv2d_desc *d) {
     TSOD_REQUIRE(d != nullptr, TSOD_ERR_INVALID_ARG);
@@ -416,7 +422,7 @@ int cu_count() {
 }
 
 // Workgroups that fit on one CU at a time (LDS-bound: 2 stages of (BM+BN) x 36 floats out of 160 KiB).
-int residency(int tile) { return tile == TSOD_TILE_64x64 ? 4 : 2; }
+int residency(int tile) { return kTiles[tile].resident; }
 
 struct Sched {
     int tile, bm, bn, tiles_m, tiles_n, tiles, dp_tiles, rem_tiles, split, ksteps_per_split, grid;
@@ -490,9 +496,9 @@ Sched resolve(const tsod_conv2d_desc *d) {
     return best;
 }
 
-template <int BM, int BN, int MW>
+template <int BM, int BN, int WM, int WN, int MW>
 void launch_tile(const ConvParams &p, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MW>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MW>), dim3(grid), dim3(64 * (BM / WM) * (BN / WN)), 0, s, p);
 }
 
 }  // namespace
@@ -563,10 +569,13 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
     if (sc.rem_tiles > 0) TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= sc.ws_bytes, TSOD_ERR_WORKSPACE);
     hipStream_t s = tsod_stream(stream);
     switch (sc.tile) {
-        case TSOD_TILE_128x128: launch_tile<128, 128, 2>(p, sc.grid, s); break;
-        case TSOD_TILE_128x64: launch_tile<128, 64, 2>(p, sc.grid, s); break;
-        case TSOD_TILE_64x128: launch_tile<64, 128, 2>(p, sc.grid, s); break;
-        default: launch_tile<64, 64, 4>(p, sc.grid, s); break;
+        case TSOD_TILE_128x128: launch_tile<128, 128, 64, 64, 2>(p, sc.grid, s); break;
+        case TSOD_TILE_128x64: launch_tile<128, 64, 64, 32, 2>(p, sc.grid, s); break;
+        case TSOD_TILE_64x128: launch_tile<64, 128, 32, 64, 2>(p, sc.grid, s); break;
+        case TSOD_TILE_128x128_W8: launch_tile<128, 128, 64, 32, 4>(p, sc.grid, s); break;
+        case TSOD_TILE_128x64_W8: launch_tile<128, 64, 32, 32, 4>(p, sc.grid, s); break;
+        case TSOD_TILE_256x128_W8: launch_tile<256, 128, 64, 64, 2>(p, sc.grid, s); break;
+        default: launch_tile<64, 64, 32, 32, 4>(p, sc.grid, s); break;
     }
     if (sc.rem_tiles > 0)
     {
@@ -608,15 +617,3 @@ extern "C" int tsod_pack_conv_weight_f32(const float *w_oihw, int32_t Cout, int3
     return tsod_launch_status();
 }
 
-// Diagnostic (not part of the public ABI): occupancy the runtime grants each conv tile kernel.
-extern "C" int tsod_debug_conv_occupancy(int tile) {
-    int n = -1;
-    hipError_t e;
-    switch (tile) {
-        case TSOD_TILE_128x128: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<128, 128, 2>, 256, 0); break;
-        case TSOD_TILE_128x64: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<128, 64, 2>, 256, 0); break;
-        case TSOD_TILE_64x128: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<64, 128, 2>, 256, 0); break;
-        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<64, 64, 4>, 256, 0); break;
-    }
-    return e == hipSuccess ? n : -(int)e;
-}

@@ -148,7 +148,9 @@ class Plan:
             st.ws_bytes = lib().tsod_conv2d_workspace_bytes(byref(st.desc))
             need = max(need, st.ws_bytes)
         if self.workspace is None or self.workspace.numel() < need:
-            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            # zero-initialised: the head of the workspace holds the K-slice arrival tickets, which every
+            # launch expects to find zero and leaves zero
+            self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
         for st in self.conv_steps:
             st.args[7] = ptr(self.workspace)
             st.args[8] = self.workspace.numel()
@@ -188,7 +190,7 @@ class Plan:
         events and keep the fastest.  Purely a speed choice: every candidate computes the same sums
         in the same k order per slab; only slab boundaries move."""
         self.graph = None
-        big = torch.empty(512 << 20, dtype=torch.uint8, device=self.device)   # scratch for any split
+        big = torch.zeros(512 << 20, dtype=torch.uint8, device=self.device)   # scratch for any split (tickets zeroed)
         results = []
         for st in self.conv_steps:
             d = st.desc
@@ -196,7 +198,7 @@ class Plan:
             ksteps = (K + 31) // 32
             M = d.N * d.OH * d.OW
             cands = []
-            for tile in (1, 2, 3, 4):
+            for tile in _ffi.TILE_IDS:
                 for split in (1, -1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
                     if split > 1 and (ksteps // split < 2 or split * (M + 128) * (d.Cout + 128) * 4 > big.numel()):
                         continue
@@ -226,6 +228,20 @@ class Plan:
         del big
         self.finalize()
         return results
+
+    def export_tiles(self):
+        """[(name, tile, split_k), ...] as currently pinned in the descriptors (0 / 0 = heuristic)."""
+        return [(st.name, int(st.desc.tile), int(st.desc.split_k)) for st in self.conv_steps]
+
+    def import_tiles(self, tiles):
+        """Pin (tile, split_k) choices saved by export_tiles (same plan geometry)."""
+        if len(tiles) != len(self.conv_steps):
+            raise TsodError("tile table does not match this plan")
+        for st, (name, tile, split) in zip(self.conv_steps, tiles):
+            if name != st.name:
+                raise TsodError(f"tile table mismatch: {name} vs {st.name}")
+            st.desc.tile, st.desc.split_k = int(tile), int(split)
+        return self.finalize()
 
     def tile_choices(self):
         out = []

@@ -25,7 +25,7 @@ class _Arena:
         nbytes = max(int(nbytes), 256)
         cur = self._buf.get(device)
         if cur is None or cur.numel() < nbytes:
-            cur = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+            cur = torch.zeros(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)   # conv tickets must start at 0
             self._buf[device] = cur
         return cur
 
