@@ -53,6 +53,7 @@ struct ConvParams {
     int dp_tiles, split, ksteps_per_split;
     unsigned out_bytes, res_bytes;
     unsigned in_bytes, w_bytes;   // buffer-descriptor extents (hardware bounds check: out of range reads 0)
+    int vec_epilogue;             // 1: channels/pitches/offsets are multiples of 4 -> dwordx4 epilogue
     float neg_slope, act_hi;      // activation as min(max(v,0) + neg_slope*min(v,0), act_hi)
     float inv_cin, inv_kw;        // reciprocals for the branch-free k -> (kh, kw, ci) split
 };
@@ -270,6 +271,52 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), (short)0,
                                                                              (int)(p.res ? p.res_bytes : 0u), 0x00020000);
     const bool has_res = p.res != nullptr;
+    if (p.vec_epilogue) {
+        // Wide epilogue: each 32x32 accumulator block is transposed through a wave-private LDS patch (the staging
+        // buffers are idle now) so that a lane owns 4 consecutive output channels: residual loads and output
+        // stores become dwordx4, 8 lanes per 128-byte row segment, 4x fewer VMEM instructions than the
+        // column-per-lane form.  Only LDS ops of this wave touch the patch: in-order LDS + lgkmcnt(0) orders them.
+        float *patch = smem + wave * (32 * kLDK);
+        const int pr = lane >> 3, pc = (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + pc;           // this lane's 4 output channels
+            const bool n_ok = n < p.Cout;                        // Cout % 4 == 0 on this path: all 4 or none
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.scale && n_ok) sc = *reinterpret_cast<const float4 *>(p.scale + n);
+            if (p.shift && n_ok) sh = *reinterpret_cast<const float4 *>(p.shift + n);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + row_in) * kLDK + col_in] = acc[i][j][e];
+                const int mb = m0 + wm * WM + i * 32 + pr;
+                float4 rs[4], v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int m = mb + 8 * t;
+                    const unsigned off = (m < p.M && n_ok && has_res)
+                                             ? ((unsigned)m * (unsigned)p.res_pitch + (unsigned)(p.res_off + n)) * 4u : kOOB;
+                    rs[t] = buffer_load4(rs_res, off);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const float4 *>(patch + (pr + 8 * t) * kLDK + pc);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int m = mb + 8 * t;
+                    const unsigned off = (m < p.M && n_ok) ? ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u : kOOB;
+                    u32x4 o;
+                    o.x = __float_as_uint(apply_act(v[t].x * sc.x + sh.x + rs[t].x, p.neg_slope, p.act_hi));
+                    o.y = __float_as_uint(apply_act(v[t].y * sc.y + sh.y + rs[t].y, p.neg_slope, p.act_hi));
+                    o.z = __float_as_uint(apply_act(v[t].z * sc.z + sh.z + rs[t].z, p.neg_slope, p.act_hi));
+                    o.w = __float_as_uint(apply_act(v[t].w * sc.w + sh.w + rs[t].w, p.neg_slope, p.act_hi));
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next block overwrites it
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + col_in;
@@ -560,6 +607,9 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
         p.res_bytes = (unsigned)res_bytes;
         p.neg_slope = d->act == TSOD_ACT_NONE ? 1.f : (d->act == TSOD_ACT_PRELU ? d->slope : 0.f);
         p.act_hi = d->act == TSOD_ACT_RELU6 ? 6.f : __builtin_huge_valf();
+        p.vec_epilogue = ((d->Cout | d->out_pitch | d->out_off) & 3) == 0 && tsod_aligned16(out) &&
+                         (!residual || (((d->res_pitch | d->res_off) & 3) == 0 && tsod_aligned16(residual))) &&
+                         (!scale || tsod_aligned16(scale)) && (!shift || tsod_aligned16(shift));
         p.inv_cin = 1.0f / (float)p.Cin;
         p.inv_kw = 1.0f / (float)d->KW;
     }

@@ -85,7 +85,7 @@ roi_pool_kernel(const float *__restrict__ feat, int B, int Hf, int Wf, int C, in
 }
 
 // out [B*R][out_pitch]: mean over the PH*PW bin maxima, RoIs given in image coordinates.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 roi_pool_avg_kernel(const float *__restrict__ feat, int B, int Hf, int Wf, int C, int pitch,
                     const float *__restrict__ rois, const int *__restrict__ roi_indices, int R,
                     float img_h, float img_w, float scale, int PH, int PW, float *__restrict__ out, int out_pitch) {
@@ -142,7 +142,10 @@ extern "C" int tsod_roi_pool_avg_f32(const float *feat, int32_t B, int32_t Hf, i
     TSOD_REQUIRE((C & 3) == 0 && (feat_pitch & 3) == 0 && feat_pitch >= C && (out_pitch & 3) == 0 && out_pitch >= C,
                  TSOD_ERR_ALIGNMENT);
     TSOD_REQUIRE(tsod_aligned16(feat) && tsod_aligned16(rois) && tsod_aligned16(out), TSOD_ERR_ALIGNMENT);
-    hipLaunchKernelGGL(roi_pool_avg_kernel, dim3(B * R), dim3(256), 0, tsod_stream(stream), feat, B, Hf, Wf, C,
+    // one channel quad per thread where possible: the per-RoI work is a serial chain of window reads
+    int threads = ((C / 4 + 63) / 64) * 64;
+    threads = threads < 64 ? 64 : (threads > 1024 ? 1024 : threads);
+    hipLaunchKernelGGL(roi_pool_avg_kernel, dim3(B * R), dim3(threads), 0, tsod_stream(stream), feat, B, Hf, Wf, C,
                        feat_pitch, rois, roi_indices, R, img_h, img_w, spatial_scale, PH, PW, out, out_pitch);
     return tsod_launch_status();
 }

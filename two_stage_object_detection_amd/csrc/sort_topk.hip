@@ -2,7 +2,7 @@
 // Replaces torch.argsort(score, descending=True)[:n_pre_nms] + gathers (nets/rpn.py:56-61) and the
 // min-size compaction before it (nets/rpn.py:52-54: filtered entries arrive as key = -inf).
 //
-// One 1024-thread workgroup per image, everything in LDS after one pass over the keys:
+// One 1024-thread workgroup per image, everything in LDS:
 //   1. map f32 -> u32 "descending-orderable" d (smaller d = larger score),
 //   2. 4x8-bit MSB-first radix select of the n_sel-th smallest d (histograms in LDS),
 //   3. compaction of every d < T plus the first `need` entries with d == T in index order
@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int kThreads = 1024;
+constexpr int kThreads = 1024;              // 16 waves: the bitonic stages are LDS-latency bound, more waves hide it
 constexpr unsigned kDNegInf = 0xFF800000u;  // d(-inf)
 
 __device__ __forceinline__ unsigned desc_key(float f) {
@@ -25,27 +25,37 @@ __device__ __forceinline__ unsigned desc_key(float f) {
     return ~u;                                        // descending-orderable
 }
 
+template <int KPT>  // keys per thread held in registers: every pass after the first runs without touching memory
 __global__ void __launch_bounds__(kThreads)
 sort_topk_kernel(const float *__restrict__ keys, const float *__restrict__ boxes, int n, int n_pre, int P,
                  int *__restrict__ counts, int *__restrict__ idx_out, float *__restrict__ boxes_out,
                  float *__restrict__ keys_out) {
     extern __shared__ __align__(16) unsigned long long sm[];  // P composite keys
     __shared__ unsigned hist[256];
-    __shared__ unsigned scan[256];
     __shared__ unsigned wave_tot[kThreads / 64];
-    __shared__ unsigned s_prefix, s_need, s_nvalid, s_lt, s_eq_base;
+    __shared__ unsigned s_prefix, s_need, s_nvalid, s_cnt, s_eq_base;
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x;
     const float *k = keys + (long)b * n;
 
-    if (tid == 0) { s_nvalid = 0; s_lt = 0; s_eq_base = 0; s_prefix = 0; }
+    if (tid == 0) { s_nvalid = 0; s_cnt = 0; s_eq_base = 0; s_prefix = 0; }
+    // one pass over memory: all of this thread's loads are in flight together (a load per loop iteration in each
+    // of the six passes below was one exposed L2 round trip each, ~50 us in total)
+    unsigned dk[KPT];
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+        const int i = q * kThreads + tid;
+        dk[q] = i < n ? desc_key(k[i]) : 0xFFFFFFFFu;     // 0xFFFFFFFF (> d(-inf)) never passes a filter below
+    }
     __syncthreads();
     {
         unsigned local = 0;
-        for (int i = tid; i < n; i += kThreads) local += desc_key(k[i]) < kDNegInf ? 1u : 0u;
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) local += dk[q] < kDNegInf ? 1u : 0u;
         for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
-        if ((tid & 63) == 0 && local) atomicAdd(&s_nvalid, local);
+        if (lane == 0 && local) atomicAdd(&s_nvalid, local);
     }
     __syncthreads();
     const int n_sel = min((int)s_nvalid, n_pre);
@@ -53,78 +63,111 @@ sort_topk_kernel(const float *__restrict__ keys, const float *__restrict__ boxes
     __syncthreads();
 
     if (n_sel > 0) {
-        // ---- radix select: after the 4 passes s_prefix is the d of rank n_sel (1-based) and
-        //      s_need the number of entries equal to it that belong to the selection.
-        unsigned mask = 0;
+        // ---- radix select, MSB first: after the 4 passes s_prefix is the d of rank n_sel (1-based), s_need the
+        //      number of entries equal to it that belong to the selection, count_eq how many equal it in total.
+        unsigned mask = 0, count_eq = 0;
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
             const unsigned prefix = s_prefix;
-            for (int i = tid; i < n; i += kThreads) {
-                const unsigned d = desc_key(k[i]);
-                if ((d & mask) == prefix) atomicAdd(&hist[(d >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            if (tid < 256) scan[tid] = hist[tid];
-            __syncthreads();
-            for (int off = 1; off < 256; off <<= 1) {  // inclusive Hillis-Steele scan over 256 bins
-                unsigned v = 0;
-                if (tid < 256 && tid >= off) v = scan[tid - off];
-                __syncthreads();
-                if (tid < 256) scan[tid] += v;
-                __syncthreads();
-            }
-            const unsigned need = s_need;
-            __syncthreads();
-            if (tid < 256) {
-                const unsigned incl = scan[tid];
-                const unsigned excl = incl - hist[tid];
-                if (excl < need && need <= incl) {  // exactly one bin satisfies this
-                    s_prefix = prefix | ((unsigned)tid << shift);
-                    s_need = need - excl;
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                if (q * kThreads >= n) break;
+                const int i = q * kThreads + tid;
+                const unsigned d = dk[q];
+                bool pending = i < n && (d & mask) == prefix;
+                const unsigned bin = (d >> shift) & 255u;
+                // scores share sign/exponent bits, so the leading digits put most of a wave into a handful of
+                // bins: count each of the first few distinct bins once per wave (ballot + popcount, one LDS
+                // atomic) instead of 64 serialised same-address atomics; stragglers use plain atomics
+                for (int round = 0; round < 4; ++round) {
+                    const unsigned long long live = __ballot(pending);
+                    if (live == 0ull) break;
+                    const int leader = __ffsll((long long)live) - 1;
+                    const unsigned lb = __shfl(bin, leader);
+                    const bool same = pending && bin == lb;
+                    const unsigned long long grp = __ballot(same);
+                    if (lane == leader) atomicAdd(&hist[lb], (unsigned)__popcll(grp));
+                    pending = pending && !same;
                 }
+                if (pending) atomicAdd(&hist[bin], 1u);
+            }
+            __syncthreads();
+            // inclusive scan of the 256 bins by the first 4 waves: shuffles inside a wave, wave totals through LDS
+            const unsigned mine = tid < 256 ? hist[tid] : 0u;
+            unsigned incl = mine;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned v = __shfl_up(incl, off);
+                if (lane >= off) incl += v;
+            }
+            if (lane == 63 && wid < 4) wave_tot[wid] = incl;
+            __syncthreads();
+            for (int w = 0; w < wid && w < 4; ++w) incl += wave_tot[w];
+            const unsigned need = s_need;
+            const unsigned excl = incl - mine;
+            __syncthreads();
+            if (tid < 256 && excl < need && need <= incl) {  // exactly one bin satisfies this
+                s_prefix = prefix | ((unsigned)tid << shift);
+                s_need = need - excl;
+                if (shift == 0) s_eq_base = mine;   // entries equal to the threshold value
             }
             mask |= 0xFFu << shift;
             __syncthreads();
         }
         const unsigned T = s_prefix;
         const unsigned need_eq = s_need;
+        count_eq = s_eq_base;
         const unsigned count_lt = (unsigned)n_sel - need_eq;
-
-        // ---- compaction.  d < T: any slot in [0, count_lt) (the sort fixes the order);
-        //      d == T: slot count_lt + rank-among-equals, rank taken in index order.
-        for (int base = 0; base < n; base += kThreads) {
-            const int i = base + tid;
-            const unsigned d = i < n ? desc_key(k[i]) : 0xFFFFFFFFu;
-            if (i < n && d < T) {
-                const unsigned pos = atomicAdd(&s_lt, 1u);
-                sm[pos] = ((unsigned long long)d << 32) | (unsigned)i;
-            }
-            const bool is_eq = (i < n) && (d == T);
-            const unsigned long long bal = __ballot(is_eq);
-            const unsigned in_wave = __popcll(bal & ((1ull << (tid & 63)) - 1ull));
-            if ((tid & 63) == 0) wave_tot[tid >> 6] = (unsigned)__popcll(bal);
-            __syncthreads();
-            unsigned before = s_eq_base, total = 0;
-            for (int w = 0; w < kThreads / 64; ++w) {
-                const unsigned t = wave_tot[w];
-                if (w < (tid >> 6)) before += t;
-                total += t;
-            }
-            const unsigned rank = before + in_wave;
-            if (is_eq && rank < need_eq) sm[count_lt + rank] = ((unsigned long long)d << 32) | (unsigned)i;
-            __syncthreads();
-            if (tid == 0) s_eq_base += total;
-            __syncthreads();
-        }
-        for (int i = n_sel + tid; i < P; i += kThreads) sm[i] = ~0ull;
+        __syncthreads();
+        if (tid == 0) s_eq_base = 0;
         __syncthreads();
 
-        // ---- bitonic sort, ascending in the composite key.
-        for (int kk = 2; kk <= P; kk <<= 1) {
-            for (int j = kk >> 1; j > 0; j >>= 1) {
-                for (int t = tid; t < (P >> 1); t += kThreads) {
-                    const int lo = ((t / j) * (j << 1)) + (t % j);
+        if (need_eq == count_eq) {
+            // common case: the whole tie group at the threshold is selected -> any slot will do, the sort
+            // below orders by (d, index)
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                const int i = q * kThreads + tid;
+                const unsigned d = dk[q];
+                if (i < n && d <= T) sm[atomicAdd(&s_cnt, 1u)] = ((unsigned long long)d << 32) | (unsigned)i;
+            }
+        } else {
+            // the tie group straddles the cut: take its first need_eq members in index order (stable rule)
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                if (q * kThreads >= n) break;
+                const int i = q * kThreads + tid;
+                const unsigned d = dk[q];
+                if (i < n && d < T) sm[atomicAdd(&s_cnt, 1u)] = ((unsigned long long)d << 32) | (unsigned)i;
+                const bool is_eq = (i < n) && (d == T);
+                const unsigned long long bal = __ballot(is_eq);
+                const unsigned in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) wave_tot[wid] = (unsigned)__popcll(bal);
+                __syncthreads();
+                unsigned before = s_eq_base, total = 0;
+                for (int w = 0; w < kThreads / 64; ++w) {
+                    const unsigned t = wave_tot[w];
+                    if (w < wid) before += t;
+                    total += t;
+                }
+                const unsigned rank = before + in_wave;
+                if (is_eq && rank < need_eq) sm[count_lt + rank] = ((unsigned long long)d << 32) | (unsigned)i;
+                __syncthreads();
+                if (tid == 0) s_eq_base += total;
+                __syncthreads();
+            }
+        }
+        int Ps = 2;                       // sort only the power of two that covers the selection
+        while (Ps < n_sel) Ps <<= 1;
+        for (int i = n_sel + tid; i < Ps; i += kThreads) sm[i] = ~0ull;
+        __syncthreads();
+
+        // ---- bitonic sort, ascending in the composite key (j = 2^lj: shifts, no integer division).
+        for (int kk = 2; kk <= Ps; kk <<= 1) {
+            for (int lj = 31 - __clz(kk >> 1); lj >= 0; --lj) {
+                const int j = 1 << lj;
+                for (int t = tid; t < (Ps >> 1); t += kThreads) {
+                    const int lo = ((t >> lj) << (lj + 1)) | (t & (j - 1));
                     const int hi = lo + j;
                     const unsigned long long a = sm[lo], c = sm[hi];
                     const bool up = (lo & kk) == 0;
@@ -156,21 +199,28 @@ extern "C" int tsod_sort_topk_desc_f32(const float *keys, const float *boxes, in
                                        tsod_stream_t stream) {
     TSOD_REQUIRE(keys && counts && idx, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(B > 0 && n > 0 && n_pre > 0, TSOD_ERR_INVALID_ARG);
-    TSOD_REQUIRE(n_pre <= 16384, TSOD_ERR_UNSUPPORTED);
+    TSOD_REQUIRE(n_pre <= 16384 && n <= 80 * kThreads, TSOD_ERR_UNSUPPORTED);
     TSOD_REQUIRE(boxes_out == nullptr || boxes != nullptr, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE((boxes == nullptr || tsod_aligned16(boxes)) && (boxes_out == nullptr || tsod_aligned16(boxes_out)),
                  TSOD_ERR_ALIGNMENT);
     int P = 2;
     while (P < n_pre) P <<= 1;
     const size_t lds = (size_t)P * sizeof(unsigned long long);
-    if (lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(sort_topk_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return TSOD_ERR_UNSUPPORTED;
-        }
-    }
-    hipLaunchKernelGGL(sort_topk_kernel, dim3(B), dim3(kThreads), lds, tsod_stream(stream), keys, boxes, n, n_pre, P,
-                       counts, idx, boxes_out, keys_out);
+#define TSOD_SORT(KPT)                                                                                                 \
+    do {                                                                                                               \
+        if (lds > 48 * 1024 &&                                                                                         \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(sort_topk_kernel<KPT>),                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {                 \
+            (void)hipGetLastError();                                                                                   \
+            return TSOD_ERR_UNSUPPORTED;                                                                               \
+        }                                                                                                              \
+        hipLaunchKernelGGL(sort_topk_kernel<KPT>, dim3(B), dim3(kThreads), lds, tsod_stream(stream), keys, boxes, n,  \
+                           n_pre, P, counts, idx, boxes_out, keys_out);                                                \
+    } while (0)
+    if (n <= 10 * kThreads) TSOD_SORT(10);
+    else if (n <= 20 * kThreads) TSOD_SORT(20);
+    else if (n <= 40 * kThreads) TSOD_SORT(40);
+    else TSOD_SORT(80);
+#undef TSOD_SORT
     return tsod_launch_status();
 }
