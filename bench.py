@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the real path) | gloo (rehearsal of "
+                    "the N>1 control flow on a box with fewer GPUs than ranks: ranks share devices, gather goes through host)")
     return ap.parse_args()
 
 
@@ -99,10 +101,14 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     n_gpus = world if world > 1 else 1
     assert torch.cuda.is_available(), "bench.py needs a GPU (the package has no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from two_stage_object_detection_amd import hip_ops
     from two_stage_object_detection_amd.dist import all_gather_detections
@@ -138,12 +144,13 @@ def main():
         gathered = None
         if world > 1:
             R = step().shape[1]
-            gathered = torch.empty((world * B, R, 6), dtype=torch.float32, device=dev)
+            gathered = torch.empty((world * B, R, 6), dtype=torch.float32,
+                                   device=dev if args.dist_backend == "nccl" else "cpu")
 
         def full_step():
             det = step()
             if world > 1:
-                all_gather_detections(det, out=gathered)
+                all_gather_detections(det if args.dist_backend == "nccl" else det.cpu(), out=gathered)
             return det
 
         for _ in range(max(args.warmup, 1)):
@@ -162,7 +169,7 @@ def main():
         elapsed = time.perf_counter() - t0
         model.raise_if_error()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -181,7 +188,8 @@ def main():
             "config": {"workload": f"Full Faster R-CNN {args.backbone} inference forward, batch={B} per GPU, "
                                    f"3x{args.height}x{args.width}, {args.num_classes}+1 classes, 3000->300 proposals",
                        "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}",
-                       "hip_graph": not args.no_graph, "autotuned_tiles": not args.no_autotune},
+                       "hip_graph": not args.no_graph, "autotuned_tiles": not args.no_autotune,
+                       "collective": None if n_gpus == 1 else f"all_gather_into_tensor [{n_gpus * B},300,6] f32 ({args.dist_backend})"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel": f"conv_igemm_kernel (f32 MFMA implicit GEMM), {len(conv_ms)} launches per forward",

@@ -134,7 +134,7 @@ class Plan:
         self.steps.append([lib().tsod_conv2d_f32, args])
         st = ConvStep()
         st.desc, st.args, st.name = d, args, name
-        st.flops = 2 * N * OH * OW * pc.cout * pc.kh * pc.kw_logical * pc.cin_src
+        st.flops = 2 * N * OH * OW * getattr(pc, "cout_real", pc.cout) * pc.kh * pc.kw_logical * pc.cin_src   # algorithmic
         st.ws_bytes = 0
         self.conv_steps.append(st)
         self.flops += st.flops

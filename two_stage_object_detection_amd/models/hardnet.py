@@ -146,10 +146,11 @@ def _padded(v: torch.Tensor, n: int, fill=0.0):
 class _RawConv:
     """PackedConv-compatible holder for a pre-gathered 1x1 weight."""
 
-    def __init__(self, w_packed, scale, shift, device, act):
+    def __init__(self, w_packed, scale, shift, device, act, cin_real=None, cout_real=None):
         self.w = w_packed.to(device)
         self.cout, self.kh, self.kw, self.cin = self.w.shape
-        self.kw_logical, self.cin_src = self.kw, self.cin
+        self.kw_logical, self.cin_src = self.kw, (self.cin if cin_real is None else cin_real)   # for FLOP accounting
+        self.cout_real = self.cout if cout_real is None else cout_real
         self.stride, self.pad, self.act, self.slope = 1, 0, act, 0.0
         self.scale = None if scale is None else scale.to(device)
         self.shift = None if shift is None else shift.to(device)
@@ -270,7 +271,8 @@ class HarDNetFeatureExtraction(nn.Module):
                     cout, cp = real[li], _pad4(real[li])
                     wg = _gathered_weight(comb.layer1.conv.weight, [real[k] for k in link], cp)
                     sc, sh = fold_bn(comb.layer1.norm)
-                    rc = _RawConv(wg, _padded(sc, cp), _padded(sh, cp), device, ACT_RELU6)
+                    rc = _RawConv(wg, _padded(sc, cp), _padded(sh, cp), device, ACT_RELU6,
+                                  cin_real=sum(real[k] for k in link), cout_real=cout)
                     tmp = plan.pool.alloc((N, h, w, cp))
                     plan.conv(rc, buf, tmp, segs=segs, name=f"base.{i}.layers.{li - 1}.layer1")
                     emit_dw(tmp, 0, cout, comb.layer2.dwconv, comb.layer2.norm, 1, False, buf, offs[li],
@@ -284,7 +286,7 @@ class HarDNetFeatureExtraction(nn.Module):
                 tr = mods[i]
                 wg = _gathered_weight(tr.conv.weight, [real[k] for k in outs], tr.conv.weight.shape[0])
                 sc, sh = fold_bn(tr.norm)
-                rc = _RawConv(wg, sc, sh, device, ACT_RELU6)
+                rc = _RawConv(wg, sc, sh, device, ACT_RELU6, cin_real=sum(real[k] for k in outs))
                 dst, dst_off = dest_for(i + 1, rc.cout, h, w)
                 if isinstance(mods[i + 1], DWConvLayer):          # "downsample" dw3x3 at stride 1 follows
                     plan.pool.release(dst)
