@@ -180,6 +180,59 @@ def test_detector_end_to_end(dev, synth, backbone, shape, ncls):
         assert rep["rows_positional_mismatch"] == 0 and rep["rows_unmatched"] == 0, rep   # well-separated scores: exact
 
 
+def test_config3_batch16_full_size(dev, synth):
+    """BASELINE config 3: batch 16 at 3x800x1333 (RoI-pool + wavefront-NMS stress).  Every image is checked against
+    the oracle; the batched GPU result must also match single-image GPU runs (images are independent units:
+    that is what the data-parallel sharding relies on)."""
+    from two_stage_object_detection_amd.testing import compare_detector_outputs
+    model, sd = synth("resnet50", 80)
+    x = _img((16, 3, 800, 1333), seed=77)
+    with torch.inference_mode():
+        got = [o.cpu() for o in model(x.to(dev))]
+        model.raise_if_error()
+        singles = [[o.cpu() for o in model(x[i:i + 1].to(dev))] for i in (0, 7, 15)]
+        ref = oracle.detector_forward(sd, x[:4], backbone="resnet50")       # oracle on the first 4 images (CPU time)
+    # images are independent units; the K-slice schedule (hence the f32 summation order) depends on the batch size,
+    # so batched vs single-image results agree to the parity bars, not bit for bit
+    for i, s in zip((0, 7, 15), singles):
+        r = compare_detector_outputs([got[0][i:i + 1], got[1][i:i + 1], got[2][i:i + 1], got[3][:1]], s)
+        assert r["ok"], (i, r)
+    rep = compare_detector_outputs([got[0][:4], got[1][:4], got[2][:4], got[3][:4]], ref)
+    print("config3", rep)
+    assert rep["ok"], rep
+
+
+def test_train_mode_12000_to_600(dev, synth):
+    """mode="train" selects 12000 -> 600; HarDNet stride 16 gives 37800 anchors at 800x1333."""
+    from two_stage_object_detection_amd.testing import compare_detector_outputs
+    model, sd = synth("hardnet39", 20, "train")
+    x = _img((1, 3, 800, 1333), seed=5)
+    with torch.inference_mode():
+        ref = oracle.detector_forward(sd, x, backbone="hardnet39", mode="train")
+        got = [o.cpu() for o in model(x.to(dev))]
+        model.raise_if_error()
+    assert got[2].shape == (1, 600, 4)
+    rep = compare_detector_outputs(got, ref)
+    print("train-mode", rep)
+    assert rep["ok"], rep
+
+
+def test_odd_geometry_and_ragged_batch(dev, synth):
+    """Sizes that are not multiples of the stride / tile sizes, and a batch whose images have very different
+    numbers of valid proposals (one image is blank: its proposals come only from the biases)."""
+    from two_stage_object_detection_amd.testing import compare_detector_outputs
+    model, sd = synth("resnet50")
+    x = _img((3, 3, 331, 517), seed=9)
+    x[1].zero_()
+    with torch.inference_mode():
+        ref = oracle.detector_forward(sd, x, backbone="resnet50")
+        got = [o.cpu() for o in model(x.to(dev))]
+        model.raise_if_error()
+    rep = compare_detector_outputs(got, ref)
+    print("odd", rep)
+    assert rep["ok"], rep
+
+
 def test_forward_modes_surface(dev, synth):
     """mode = extractor / rpn / head of nets/frcnn.py:41-54 (with the 5-tuple the reference intends)."""
     model, sd = synth("resnet50")
