@@ -19,4 +19,4 @@ from .box import (  # noqa: F401
     nms, roi_pool, proposal_layer, rpn_forward, roi_head_forward,
 )
 from .backbones import resnet_trunk, hardnet_trunk, calibrate_bn  # noqa: F401
-from .detector import detector_forward, detections_from_outputs  # noqa: F401
+from .detector import detector_forward, detections_from_outputs, postprocess  # noqa: F401

@@ -61,3 +61,15 @@ def detections_from_outputs(roi_cls_locs, roi_scores, rois):
     sel = torch.gather(locs, 2, cls.view(B, R, 1, 1).expand(B, R, 1, 4)).squeeze(2)
     boxes = loc2bbox(rois.reshape(-1, 4), sel.reshape(-1, 4)).view(B, R, 4)
     return torch.cat([boxes, score.unsqueeze(-1), cls.to(boxes.dtype).unsqueeze(-1)], dim=-1)
+
+
+def postprocess(det, iou_threshold=0.1):
+    """multi_inference.py:80-87 for a batch of detection records [B,R,6]: per image
+    ``keep = nms(boxes_pred, labels_score_pred, iou_threshold)`` (class-agnostic).  Returns a list of kept
+    record tensors, each in descending-score order (what ``boxes_pred[keep]`` etc. are in the reference)."""
+    from .box import nms
+    out = []
+    for d in det:
+        keep = nms(d[:, :4], d[:, 4], iou_threshold)
+        out.append(d[keep])
+    return out

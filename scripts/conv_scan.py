@@ -15,7 +15,8 @@ for W in [int(v) for v in sys.argv[5:]]:
     x = torch.randn(1, 64, W, Cin, device=dev)
     w = torch.randn(Cout, k, k, Cin, device=dev) / (Cin * k * k) ** 0.5
     M = 64 * W
-    for split in (1, -1):
+    import os
+    for split in [int(v) for v in os.environ.get("SPLITS", "1,-1").split(",")]:
         t = timeit(lambda: hip_ops.conv2d_nhwc(x, w, pad=k // 2, tile=tile, split_k=split))
         fl = 2 * M * Cout * Cin * k * k
         print(f"M={M:6d} tiles64={M//64:5d} split {split:2d}: {t*1e3:7.1f} us  {fl/t/1e9:6.1f} TF/s", flush=True)

@@ -233,6 +233,23 @@ def test_odd_geometry_and_ragged_batch(dev, synth):
     assert rep["ok"], rep
 
 
+def test_postprocess_nms_like_the_demo_script(dev, synth):
+    """the step after the path - multi_inference.py:84's class-agnostic NMS(0.1) over the records."""
+    model, sd = synth("resnet50")
+    g = torch.Generator().manual_seed(31)
+    # records with heavy overlap so that NMS at 0.1 really prunes; fed to both sides (stage-wise)
+    xy = torch.rand(2, 300, 2, generator=g) * 300
+    det = torch.cat([xy, xy + torch.rand(2, 300, 2, generator=g) * 200 + 5, torch.randn(2, 300, 1, generator=g),
+                     torch.randint(0, 21, (2, 300, 1), generator=g).float()], dim=-1)
+    ref = oracle.postprocess(det, 0.1)
+    det_sorted, keep, n_kept = model.postprocess(det.to(dev), 0.1)
+    for b in range(2):
+        k = int(n_kept[b])
+        assert k == ref[b].shape[0] and 0 < k < 300
+        got = det_sorted[b][keep[b, :k].long()].cpu()
+        assert torch.equal(got, ref[b])
+
+
 def test_forward_modes_surface(dev, synth):
     """mode = extractor / rpn / head of nets/frcnn.py:41-54 (with the 5-tuple the reference intends)."""
     model, sd = synth("resnet50")

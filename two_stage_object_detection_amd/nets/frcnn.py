@@ -71,6 +71,32 @@ class FasterRCNN(nn.Module):
         cls_locs, scores, rois, _ = self.forward(x, scale)
         return hip_ops.detections(cls_locs, scores, rois)
 
+    def load_trainer_checkpoint(self, ckpt, strict=True):
+        """Load weights saved by the reference's training script (train/train.py:120-128 writes
+        ``{'model_state_dict': FasterRCNNTrainer.state_dict(), ...}``; the trainer names the backbone
+        ``feat_extra`` where this module - like nets/frcnn.py:15 - says ``extractor``).  ``ckpt`` is a path
+        (loaded with weights_only=True, as train/train.py:60-71 does) or an already loaded dict."""
+        if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
+            ckpt = torch.load(ckpt, map_location="cpu", weights_only=True)
+        sd = ckpt.get("model_state_dict", ckpt)
+        remapped = {("extractor." + k[len("feat_extra."):] if k.startswith("feat_extra.") else k): v for k, v in sd.items()}
+        return self.load_state_dict(remapped, strict=strict)
+
+    def postprocess(self, det, iou_threshold=0.1):
+        """The inference-time filtering of the reference's demo script (multi_inference.py:80-87): per image,
+        class-agnostic ``nms(boxes_pred, labels_score_pred, iou_threshold)`` over the decoded per-RoI boxes with the
+        arg-max logit as score.  det [B,R,6] from ``detections()`` -> (det_sorted [B,R,6] in descending-score order,
+        keep [B,R] int32 indices into det_sorted, n_kept [B] int32): the survivors of image b are
+        ``det_sorted[b][keep[b, :n_kept[b]].long()]``.  Same HIP kernels as the proposal path (top-k sort + bitmask NMS)."""
+        require_cuda(det, "FasterRCNN.postprocess")
+        B, R, _ = det.shape
+        boxes = det[..., :4].contiguous()
+        scores = det[..., 4].contiguous()
+        counts, idx, boxes_sorted, _ = hip_ops.sort_topk_desc(scores, boxes, R)
+        keep, _, n_kept, _ = hip_ops.nms_sorted(boxes_sorted, counts, iou_threshold, R)
+        det_sorted = torch.gather(det, 1, idx.long().clamp_min(0).unsqueeze(-1).expand(B, R, 6))   # layout plumbing only
+        return det_sorted, keep, n_kept
+
     def make_graphed(self, x_example):
         """Capture forward + detection records for this input geometry into ONE HIP graph.
         Returns (run, static_input, static_outputs): copy images into ``static_input`` (or pass them
