@@ -16,16 +16,18 @@ from ._ffi import ACT_NONE, check, lib, make_conv_desc, ptr, require_cuda, strea
 
 # ----------------------------------------------------------------------------- workspace arena
 class _Arena:
-    """One growable scratch tensor per device (split-K slabs, NMS masks)."""
+    """One growable scratch tensor per (device, stream) (split-K slabs, NMS masks)."""
 
     def __init__(self):
         self._buf = {}
 
     def get(self, device, nbytes: int) -> torch.Tensor:
         nbytes = max(int(nbytes), 256)
+        # one scratch buffer per (device, stream): forwards in flight on different streams must not share slabs
+        device = (device, torch.cuda.current_stream(device).cuda_stream)
         cur = self._buf.get(device)
         if cur is None or cur.numel() < nbytes:
-            cur = torch.zeros(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)   # conv tickets must start at 0
+            cur = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device[0])
             self._buf[device] = cur
         return cur
 

@@ -326,11 +326,11 @@ class HarDNetFeatureExtraction(nn.Module):
         plan.output_nhwc = cur
         return plan.finalize()
 
-    def _plan_for(self, x):
+    def _plan_for(self, x, slot: int = 0):
         require_cuda(x, "HarDNetFeatureExtraction.forward")
         if x.dim() != 4 or x.shape[1] != 3:
             raise TsodError(f"expected [N,3,H,W], got {tuple(x.shape)}")
-        key = (tuple(x.shape), x.device)
+        key = (tuple(x.shape), x.device, slot)       # slot: independent buffer sets for forwards in flight concurrently
         plan = self._plans.get(key)
         if plan is None:
             if self.training:
@@ -339,8 +339,8 @@ class HarDNetFeatureExtraction(nn.Module):
             self._plans[key] = plan
         return plan
 
-    def forward_nhwc(self, x):
-        plan = self._plan_for(x)
+    def forward_nhwc(self, x, slot: int = 0):
+        plan = self._plan_for(x, slot)
         x = x.contiguous()
         N, _, H, W = x.shape
         hip_ops.check(lib().tsod_nchw_to_nhwc_f32(ptr(x), N, 3, H, W, ptr(plan.input_nhwc), 4, 4, hip_ops.stream_ptr()),

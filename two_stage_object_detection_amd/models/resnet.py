@@ -157,11 +157,11 @@ class ResNet(nn.Module):
         plan.output_nhwc = cur
         return plan.finalize()
 
-    def _plan_for(self, x: torch.Tensor) -> Plan:
+    def _plan_for(self, x: torch.Tensor, slot: int = 0) -> Plan:
         require_cuda(x, "ResNet.forward")
         if x.dim() != 4 or x.shape[1] != 3:
             raise TsodError(f"expected [N,3,H,W], got {tuple(x.shape)}")
-        key = (tuple(x.shape), x.device)
+        key = (tuple(x.shape), x.device, slot)       # slot: independent buffer sets for forwards in flight concurrently
         plan = self._plans.get(key)
         if plan is None:
             if self.training:
@@ -170,9 +170,9 @@ class ResNet(nn.Module):
             self._plans[key] = plan
         return plan
 
-    def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+    def forward_nhwc(self, x: torch.Tensor, slot: int = 0) -> torch.Tensor:
         """[N,3,H,W] -> NHWC feature [N,H/32,W/32,C] (plan-owned buffer, valid until the next forward)."""
-        plan = self._plan_for(x)
+        plan = self._plan_for(x, slot)
         x = x.contiguous()
         N, _, H, W = x.shape
         hip_ops.check(lib().tsod_nchw_to_nhwc_f32(ptr(x), N, 3, H, W, ptr(plan.input_nhwc), 4, 4, hip_ops.stream_ptr()),

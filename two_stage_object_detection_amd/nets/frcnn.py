@@ -46,10 +46,12 @@ class FasterRCNN(nn.Module):
         self.head = HarNetRoIHead(n_class=num_classes + 1, roi_size=7, spatial_scale=1, classifier=self.classifier,
                                   in_channels=feat_ch)
 
-    def forward(self, x, scale=1., mode="forward"):
+    def forward(self, x, scale=1., mode="forward", slot=0):
+        """``slot`` (added, non-breaking) selects an independent set of backbone buffers, so that forwards issued on
+        different HIP streams can be in flight together."""
         if mode == "forward":
             require_cuda(x, "FasterRCNN.forward")
-            feat = self.extractor.forward_nhwc(x)
+            feat = self.extractor.forward_nhwc(x, slot)
             _, _, rois, _ = self.rpn.forward_nhwc(feat, tuple(x.shape[1:]), scale)
             roi_indices = torch.arange(x.shape[0], dtype=torch.int32, device=x.device)
             roi_cls_locs, roi_scores = self.head.forward_nhwc(feat, rois, roi_indices, tuple(x.shape[2:]))
@@ -97,7 +99,7 @@ class FasterRCNN(nn.Module):
         det_sorted = torch.gather(det, 1, idx.long().clamp_min(0).unsqueeze(-1).expand(B, R, 6))   # layout plumbing only
         return det_sorted, keep, n_kept
 
-    def make_graphed(self, x_example):
+    def make_graphed(self, x_example, slot=0):
         """Capture forward + detection records for this input geometry into ONE HIP graph.
         Returns (run, static_input, static_outputs): copy images into ``static_input`` (or pass them
         to ``run(x)``), call ``run()``, read ``static_outputs`` = (roi_cls_locs, roi_scores, rois,
@@ -109,12 +111,12 @@ class FasterRCNN(nn.Module):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.inference_mode():
             for _ in range(2):                                   # builds plans, sizes workspaces
-                outs = self.forward(static_in)
+                outs = self.forward(static_in, slot=slot)
                 hip_ops.detections(outs[0], outs[1], outs[2])
         side.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.inference_mode(), torch.cuda.graph(graph, stream=side):
-            outs = self.forward(static_in)
+            outs = self.forward(static_in, slot=slot)
             det = hip_ops.detections(outs[0], outs[1], outs[2])
         static_out = tuple(outs) + (det,)
 
