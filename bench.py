@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--num-classes", type=int, default=80)
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--autotune-splits", default=None, help="comma list restricting the K-slice candidates of the autotuner")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--in-flight", type=int, default=4, help="steps in flight: consecutive steps are issued round-robin on this "
                     "many HIP streams, each with its own graph and buffers (request-level pipelining of a batch-1 server)")
@@ -132,7 +133,8 @@ def main():
         if args.tiles_file and os.path.exists(args.tiles_file):
             plan.import_tiles(json.load(open(args.tiles_file)))
         elif not args.no_autotune:
-            plan.autotune(verbose=args.verbose and rank == 0)
+            plan.autotune(verbose=args.verbose and rank == 0,
+                          splits=[int(v) for v in args.autotune_splits.split(",")] if args.autotune_splits else None)
             if args.tiles_file and rank == 0:
                 json.dump(plan.export_tiles(), open(args.tiles_file, "w"))
         conv_ms = conv_event_times(plan)

@@ -185,7 +185,7 @@ class Plan:
         return self
 
     # -- tile autotuning ----------------------------------------------------------------------
-    def autotune(self, reps: int = 3, verbose: bool = False):
+    def autotune(self, reps: int = 3, verbose: bool = False, splits=None):
         """Measure every (tile, split_k) candidate of every conv step on the real buffers with HIP
         events and keep the fastest.  Purely a speed choice: every candidate computes the same sums
         in the same k order per slab; only slab boundaries move."""
@@ -199,7 +199,7 @@ class Plan:
             M = d.N * d.OH * d.OW
             cands = []
             for tile in _ffi.TILE_IDS:
-                for split in (1, -1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+                for split in (splits or (1, -1, 2, 3, 4, 6, 8, 12, 16, 24, 32)):
                     if split > 1 and (ksteps // split < 2 or split * (M + 128) * (d.Cout + 128) * 4 > big.numel()):
                         continue
                     cands.append((tile, split))
