@@ -80,7 +80,10 @@ __device__ __forceinline__ int seg_channel(const ConvParams &p, int ci) {
 }
 
 // BM x BN workgroup tile, WM x WN per-wave tile: (BM/WM) x (BN/WN) waves of 64 lanes.
-template <int BM, int BN, int WM, int WN, int MIN_WAVES>
+// NBUF = 2: double-buffered LDS (the next K-step is staged under the MFMAs); NBUF = 1: one LDS buffer, the next
+// K-step waits in registers and is written between two barriers - half the LDS and fewer registers per workgroup,
+// so more workgroups share a CU (more waves per SIMD to cover each other's waits, finer-grained chip filling).
+template <int BM, int BN, int WM, int WN, int MIN_WAVES, int NBUF = 2>
 __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_igemm_kernel(const ConvParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int THREADS = 64 * (BM / WM) * WAVES_N;
@@ -89,7 +92,9 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;  // rows each thread stages per K-step
     constexpr int STAGE = (BM + BN) * kLDK;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
-    __shared__ __align__(16) float smem[2 * STAGE];
+    constexpr int PATCHES = (THREADS / 64) * 32 * kLDK;                      // epilogue transpose patches, one per wave
+    constexpr int SMEM = NBUF * STAGE > PATCHES ? NBUF * STAGE : PATCHES;
+    __shared__ __align__(16) float smem[SMEM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -232,7 +237,21 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     };
 
     const int nk = kt_end - kt_begin;
-    if (nk > 0) {
+    if (NBUF == 1) {
+        if (nk > 0) {
+            load_global(ra0, rb0);
+            store_lds(0, ra0, rb0);
+            __syncthreads();
+            for (int it = 0; it < nk; ++it) {
+                const bool more = it + 1 < nk;
+                kstep(0, more, ra0, rb0, false, ra1, rb1);     // loads of step it+1 fly under the MFMAs of step it
+                if (more) {
+                    store_lds(0, ra0, rb0);                     // every wave is past the barrier that ends kstep
+                    __syncthreads();
+                }
+            }
+        }
+    } else if (nk > 0) {
         load_global(ra0, rb0);                       // step 0
         if (nk > 1) load_global(ra1, rb1);           // step 1
         store_lds(0, ra0, rb0);
@@ -423,7 +442,8 @@ pack_weight_kernel(const float *__restrict__ w, int Cout, int Cin_src, int KH, i
 struct TileInfo { int bm, bn, threads, resident; float cost; };   // resident = workgroups per CU (LDS-bound)
 const TileInfo kTiles[TSOD_TILE_COUNT] = {
     {0, 0, 0, 0, 0.f},          {128, 128, 256, 2, 1.00f}, {128, 64, 256, 2, 1.06f}, {64, 64, 256, 4, 1.15f},
-    {64, 128, 256, 2, 1.06f},   {128, 128, 512, 2, 1.00f}, {128, 64, 512, 2, 1.06f}, {256, 128, 512, 1, 0.98f}};
+    {64, 128, 256, 2, 1.06f},   {128, 128, 512, 2, 1.00f}, {128, 64, 512, 2, 1.06f}, {256, 128, 512, 1, 0.98f},
+    {64, 64, 256, 6, 1.20f},    {128, 64, 512, 3, 1.10f}};
 
 int validate(const tsod_conv2d_desc *d) {
     TSOD_REQUIRE(d != nullptr, TSOD_ERR_INVALID_ARG);
@@ -543,9 +563,9 @@ Sched resolve(const tsod_conv2d_desc *d) {
     return best;
 }
 
-template <int BM, int BN, int WM, int WN, int MW>
+template <int BM, int BN, int WM, int WN, int MW, int NBUF = 2>
 void launch_tile(const ConvParams &p, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MW>), dim3(grid), dim3(64 * (BM / WM) * (BN / WN)), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MW, NBUF>), dim3(grid), dim3(64 * (BM / WM) * (BN / WN)), 0, s, p);
 }
 
 }  // namespace
@@ -625,6 +645,8 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
         case TSOD_TILE_128x128_W8: launch_tile<128, 128, 64, 32, 4>(p, sc.grid, s); break;
         case TSOD_TILE_128x64_W8: launch_tile<128, 64, 32, 32, 4>(p, sc.grid, s); break;
         case TSOD_TILE_256x128_W8: launch_tile<256, 128, 64, 64, 2>(p, sc.grid, s); break;
+        case TSOD_TILE_64x64_S1: launch_tile<64, 64, 32, 32, 6, 1>(p, sc.grid, s); break;
+        case TSOD_TILE_128x64_W8_S1: launch_tile<128, 64, 32, 32, 6, 1>(p, sc.grid, s); break;
         default: launch_tile<64, 64, 32, 32, 4>(p, sc.grid, s); break;
     }
     if (sc.rem_tiles > 0)
