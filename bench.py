@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--num-classes", type=int, default=80)
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--autotune-concurrent", type=int, default=None, help="time autotune candidates as this many copies in "
+                    "flight on separate streams (default: 2 when --in-flight > 1, else 1)")
     ap.add_argument("--autotune-splits", default=None, help="comma list restricting the K-slice candidates of the autotuner")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--in-flight", type=int, default=4, help="steps in flight: consecutive steps are issued round-robin on this "
@@ -134,7 +136,9 @@ def main():
             plan.import_tiles(json.load(open(args.tiles_file)))
         elif not args.no_autotune:
             plan.autotune(verbose=args.verbose and rank == 0,
-                          splits=[int(v) for v in args.autotune_splits.split(",")] if args.autotune_splits else None)
+                          splits=[int(v) for v in args.autotune_splits.split(",")] if args.autotune_splits else None,
+                          concurrent=args.autotune_concurrent if args.autotune_concurrent
+                          else (2 if (args.in_flight > 1 and not args.no_graph) else 1))
             if args.tiles_file and rank == 0:
                 json.dump(plan.export_tiles(), open(args.tiles_file, "w"))
         conv_ms = conv_event_times(plan)

@@ -185,12 +185,18 @@ class Plan:
         return self
 
     # -- tile autotuning ----------------------------------------------------------------------
-    def autotune(self, reps: int = 3, verbose: bool = False, splits=None):
+    def autotune(self, reps: int = 3, verbose: bool = False, splits=None, concurrent: int = 1):
         """Measure every (tile, split_k) candidate of every conv step on the real buffers with HIP
         events and keep the fastest.  Purely a speed choice: every candidate computes the same sums
-        in the same k order per slab; only slab boundaries move."""
+        in the same k order per slab; only slab boundaries move.
+        ``concurrent`` > 1 times each candidate as that many copies in flight on separate streams
+        (per-copy time = elapsed / copies): the objective of a server that overlaps requests, where a
+        schedule that fills the whole chip for one launch is not automatically the cheapest."""
         self.graph = None
-        big = torch.zeros(512 << 20, dtype=torch.uint8, device=self.device)   # scratch for any split (tickets zeroed)
+        concurrent = max(1, int(concurrent))
+        bigs = [torch.empty(512 << 20, dtype=torch.uint8, device=self.device) for _ in range(concurrent)]
+        big = bigs[0]
+        side = [torch.cuda.Stream(self.device) for _ in range(concurrent - 1)]
         results = []
         for st in self.conv_steps:
             d = st.desc
@@ -211,13 +217,30 @@ class Plan:
                 s = stream_ptr()
                 lib().tsod_conv2d_f32(*args, s)          # warm
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(reps):
-                    rc = lib().tsod_conv2d_f32(*args, s)
-                e1.record()
+                if concurrent == 1:
+                    e0.record()
+                    for _ in range(reps):
+                        rc = lib().tsod_conv2d_f32(*args, s)
+                    e1.record()
+                else:
+                    cur = torch.cuda.current_stream(self.device)
+                    for st2 in side:
+                        st2.wait_stream(cur)
+                    e0.record()
+                    for st2 in side:
+                        st2.wait_stream(cur)
+                    for _ in range(reps):
+                        rc = lib().tsod_conv2d_f32(*args, s)
+                        for ci, st2 in enumerate(side):
+                            a2 = list(args)
+                            a2[7] = ptr(bigs[ci + 1])
+                            rc |= lib().tsod_conv2d_f32(*a2, st2.cuda_stream)
+                    for st2 in side:
+                        cur.wait_stream(st2)
+                    e1.record()
                 e1.synchronize()
                 check(rc, "autotune conv")
-                t = e0.elapsed_time(e1) / reps
+                t = e0.elapsed_time(e1) / (reps * concurrent)
                 if best is None or t < best[0]:
                     best = (t, tile, split)
             d.tile, d.split_k = best[1], best[2]
@@ -225,7 +248,7 @@ class Plan:
             if verbose:
                 print(f"  {st.name:34s} {TILE_NAMES[best[1]]:8s} split {best[2]:3d}  {best[0] * 1e3:8.1f} us "
                       f"{st.flops / best[0] / 1e9:7.1f} TF/s")
-        del big
+        del big, bigs
         self.finalize()
         return results
 
