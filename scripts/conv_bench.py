@@ -29,7 +29,7 @@ for name, H, W, Cin, Cout, k, s in shapes:
     res = torch.randn(B, H, W, Cout, device=dev)
     flops = 2 * B * H * W * Cout * Cin * k * k
     out = []
-    for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
         for split in (1, -1, 2, 4, 8):
             K = Cin * k * k
             if split > 1 and (K // 32) // split < 2: continue

@@ -59,7 +59,7 @@ def _conv_ref(x, w, stride, pad):
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_conv_matches_cpu(ops, dev, case, tile):
     N, H, W, Cin, Cout, k, stride, pad = case
     g = torch.Generator().manual_seed(hash(case) % 1000)

@@ -34,8 +34,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kBK = 32;   // floats per K-step
-constexpr int kLDK = 36;  // LDS row pitch in floats (32 + 4 pad)
+constexpr int kPatchLD = 36;  // row pitch (floats) of the epilogue transpose patches
 
 struct ConvParams {
     const float *in, *w, *scale, *shift, *res;
@@ -83,16 +82,20 @@ __device__ __forceinline__ int seg_channel(const ConvParams &p, int ci) {
 // NBUF = 2: double-buffered LDS (the next K-step is staged under the MFMAs); NBUF = 1: one LDS buffer, the next
 // K-step waits in registers and is written between two barriers - half the LDS and fewer registers per workgroup,
 // so more workgroups share a CU (more waves per SIMD to cover each other's waits, finer-grained chip filling).
-template <int BM, int BN, int WM, int WN, int MIN_WAVES, int NBUF = 2>
+// BK = floats per K-step (32 or 64): LDS rows are BK + 4 floats (pitch = 4 mod 64 banks: every 16-lane group of
+// ds_read_b128 hits 16 distinct 4-bank slots); a longer step halves the barriers per FLOP of long-K (3x3) layers.
+template <int BM, int BN, int WM, int WN, int MIN_WAVES, int NBUF = 2, int BK = 32>
 __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_igemm_kernel(const ConvParams p) {
+    constexpr int kBK = BK, kLDK = BK + 4;
+    constexpr int TPR = BK / 4;                        // threads per staged row (16-byte chunks)
     constexpr int WAVES_N = BN / WN;
     constexpr int THREADS = 64 * (BM / WM) * WAVES_N;
-    constexpr int RPP = THREADS / 8;                   // rows staged per pass (8 threads cover one 128-byte row)
+    constexpr int RPP = THREADS / TPR;                 // rows staged per pass
     constexpr int TM = WM / 32, TN = WN / 32;          // 32x32 MFMA tiles per wave in m / n
     constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;  // rows each thread stages per K-step
     constexpr int STAGE = (BM + BN) * kLDK;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
-    constexpr int PATCHES = (THREADS / 64) * 32 * kLDK;                      // epilogue transpose patches, one per wave
+    constexpr int PATCHES = (THREADS / 64) * 32 * kPatchLD;                      // epilogue transpose patches, one per wave
     constexpr int SMEM = NBUF * STAGE > PATCHES ? NBUF * STAGE : PATCHES;
     __shared__ __align__(16) float smem[SMEM];
 
@@ -124,8 +127,8 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     // ---- per-thread staging geometry (all offsets are 32-bit BYTE offsets into buffer descriptors)
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, (short)0, (int)p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, (short)0, (int)p.w_bytes, 0x00020000);
-    const int c4 = (tid & 7) * 4;  // k offset of this thread's chunk inside the K-step
-    const int r0 = tid >> 3;       // 0..RPP-1
+    const int c4 = (tid % TPR) * 4;  // k offset of this thread's chunk inside the K-step
+    const int r0 = tid / TPR;        // 0..RPP-1
     unsigned a_base[A_ROWS];
     int a_ih0[A_ROWS], a_iw0[A_ROWS];
 #pragma unroll
@@ -295,7 +298,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
         // buffers are idle now) so that a lane owns 4 consecutive output channels: residual loads and output
         // stores become dwordx4, 8 lanes per 128-byte row segment, 4x fewer VMEM instructions than the
         // column-per-lane form.  Only LDS ops of this wave touch the patch: in-order LDS + lgkmcnt(0) orders them.
-        float *patch = smem + wave * (32 * kLDK);
+        float *patch = smem + wave * (32 * kPatchLD);
         const int pr = lane >> 3, pc = (lane & 7) * 4;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -307,7 +310,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + row_in) * kLDK + col_in] = acc[i][j][e];
+                for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + row_in) * kPatchLD + col_in] = acc[i][j][e];
                 const int mb = m0 + wm * WM + i * 32 + pr;
                 float4 rs[4], v[4];
 #pragma unroll
@@ -319,7 +322,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const float4 *>(patch + (pr + 8 * t) * kLDK + pc);
+                for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const float4 *>(patch + (pr + 8 * t) * kPatchLD + pc);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int m = mb + 8 * t;
@@ -439,11 +442,11 @@ pack_weight_kernel(const float *__restrict__ w, int Cout, int Cin_src, int KH, i
     }
 }
 
-struct TileInfo { int bm, bn, threads, resident; float cost; };   // resident = workgroups per CU (LDS-bound)
+struct TileInfo { int bm, bn, threads, resident; float cost; int bk; };   // resident = workgroups per CU (LDS / VGPR bound)
 const TileInfo kTiles[TSOD_TILE_COUNT] = {
-    {0, 0, 0, 0, 0.f},          {128, 128, 256, 2, 1.00f}, {128, 64, 256, 2, 1.06f}, {64, 64, 256, 4, 1.15f},
-    {64, 128, 256, 2, 1.06f},   {128, 128, 512, 2, 1.00f}, {128, 64, 512, 2, 1.06f}, {256, 128, 512, 1, 0.98f},
-    {64, 64, 256, 6, 1.20f},    {128, 64, 512, 3, 1.10f}};
+    {0, 0, 0, 0, 0.f, 32},        {128, 128, 256, 2, 1.00f, 32}, {128, 64, 256, 2, 1.06f, 32}, {64, 64, 256, 4, 1.15f, 32},
+    {64, 128, 256, 2, 1.06f, 32}, {128, 128, 512, 2, 1.00f, 32}, {128, 64, 512, 2, 1.06f, 32}, {256, 128, 512, 1, 0.98f, 32},
+    {64, 64, 256, 6, 1.20f, 32},  {128, 64, 512, 3, 1.10f, 32},  {64, 64, 256, 4, 1.10f, 64},  {128, 64, 512, 2, 1.05f, 64}};
 
 int validate(const tsod_conv2d_desc *d) {
     TSOD_REQUIRE(d != nullptr, TSOD_ERR_INVALID_ARG);
@@ -504,7 +507,8 @@ Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
     Sched s;
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
     const int K = d->KH * d->KW * desc_cin(d);
-    const int ksteps = (K + kBK - 1) / kBK;
+    const int bk = kTiles[tile].bk;
+    const int ksteps = (K + bk - 1) / bk;
     s.tile = tile; s.bm = kTiles[tile].bm; s.bn = kTiles[tile].bn;
     s.tiles_m = (int)tsod_cdiv(M, s.bm); s.tiles_n = (int)tsod_cdiv(d->Cout, s.bn);
     s.tiles = s.tiles_m * s.tiles_n;
@@ -531,7 +535,7 @@ Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
     s.ws_bytes = (size_t)s.rem_tiles * split * s.bm * s.bn * sizeof(float);
     // cost, in cycles of the most loaded CU: co-resident workgroups share the CU's matrix pipes, so a wave of
     // workgroups costs (workgroups per CU) x (K-steps x BM*BN/4 MFMA cycles + fixed prologue/epilogue)
-    const double step = (double)s.bm * s.bn / 4.0 * kTiles[tile].cost;
+    const double step = (double)s.bm * s.bn / 4.0 * kTiles[tile].cost * (bk / 32);
     const double fixed = 3000.0 + (double)s.bm * s.bn / 8.0;
     const int cus = cu_count();
     double c = (double)tsod_cdiv(dp, cus) * (ksteps * step + fixed);
@@ -553,7 +557,7 @@ Sched resolve(const tsod_conv2d_desc *d) {
             continue;
         }
         const int K = d->KH * d->KW * desc_cin(d);
-        const int ksteps = (K + kBK - 1) / kBK;
+        const int ksteps = (K + kTiles[t].bk - 1) / kTiles[t].bk;
         for (int mode : {1, -1, 2, 4, 8, 16}) {
             if (mode > 1 && ksteps / mode < 2) continue;
             const Sched s = make_sched(d, t, mode);
@@ -563,9 +567,9 @@ Sched resolve(const tsod_conv2d_desc *d) {
     return best;
 }
 
-template <int BM, int BN, int WM, int WN, int MW, int NBUF = 2>
+template <int BM, int BN, int WM, int WN, int MW, int NBUF = 2, int BK = 32>
 void launch_tile(const ConvParams &p, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MW, NBUF>), dim3(grid), dim3(64 * (BM / WM) * (BN / WN)), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MW, NBUF, BK>), dim3(grid), dim3(64 * (BM / WM) * (BN / WN)), 0, s, p);
 }
 
 }  // namespace
@@ -611,7 +615,6 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
     p.res_pitch = d->res_pitch; p.res_off = d->res_off;
     p.M = d->N * d->OH * d->OW;
     p.K = d->KH * d->KW * p.Cin;
-    p.ksteps = (p.K + kBK - 1) / kBK;
     {
         const uint64_t in_bytes = (uint64_t)d->N * d->H * d->W * d->in_pitch * sizeof(float);
         const uint64_t w_bytes = (uint64_t)d->Cout * p.K * sizeof(float);
@@ -634,6 +637,7 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
         p.inv_kw = 1.0f / (float)d->KW;
     }
     const Sched sc = resolve(d);
+    p.ksteps = (p.K + kTiles[sc.tile].bk - 1) / kTiles[sc.tile].bk;
     p.tiles_m = sc.tiles_m; p.tiles_n = sc.tiles_n;
     p.dp_tiles = sc.dp_tiles; p.split = sc.split; p.ksteps_per_split = sc.ksteps_per_split;
     if (sc.rem_tiles > 0) TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= sc.ws_bytes, TSOD_ERR_WORKSPACE);
@@ -647,6 +651,8 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
         case TSOD_TILE_256x128_W8: launch_tile<256, 128, 64, 64, 2>(p, sc.grid, s); break;
         case TSOD_TILE_64x64_S1: launch_tile<64, 64, 32, 32, 6, 1>(p, sc.grid, s); break;
         case TSOD_TILE_128x64_W8_S1: launch_tile<128, 64, 32, 32, 6, 1>(p, sc.grid, s); break;
+        case TSOD_TILE_64x64_S1_K64: launch_tile<64, 64, 32, 32, 4, 1, 64>(p, sc.grid, s); break;
+        case TSOD_TILE_128x64_W8_S1_K64: launch_tile<128, 64, 32, 32, 4, 1, 64>(p, sc.grid, s); break;
         default: launch_tile<64, 64, 32, 32, 4>(p, sc.grid, s); break;
     }
     if (sc.rem_tiles > 0)
