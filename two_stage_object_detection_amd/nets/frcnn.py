@@ -46,6 +46,14 @@ class FasterRCNN(nn.Module):
         self.head = HarNetRoIHead(n_class=num_classes + 1, roi_size=7, spatial_scale=1, classifier=self.classifier,
                                   in_channels=feat_ch)
 
+    def _roi_indices(self, n, device):
+        """arange(B) int32 (frcnn_training.py:291), cached per (B, device): a constant, not a per-forward launch."""
+        cache = self.__dict__.setdefault("_roi_idx_cache", {})
+        t = cache.get((n, device))
+        if t is None:
+            t = cache[(n, device)] = torch.arange(n, dtype=torch.int32, device=device)
+        return t
+
     def forward(self, x, scale=1., mode="forward", slot=0):
         """``slot`` (added, non-breaking) selects an independent set of backbone buffers, so that forwards issued on
         different HIP streams can be in flight together."""
@@ -53,7 +61,7 @@ class FasterRCNN(nn.Module):
             require_cuda(x, "FasterRCNN.forward")
             feat = self.extractor.forward_nhwc(x, slot)
             _, _, rois, _ = self.rpn.forward_nhwc(feat, tuple(x.shape[1:]), scale)
-            roi_indices = torch.arange(x.shape[0], dtype=torch.int32, device=x.device)
+            roi_indices = self._roi_indices(x.shape[0], x.device)
             roi_cls_locs, roi_scores = self.head.forward_nhwc(feat, rois, roi_indices, tuple(x.shape[2:]))
             return roi_cls_locs, roi_scores, rois, roi_indices
         elif mode == "extractor":

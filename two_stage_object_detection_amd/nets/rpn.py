@@ -39,6 +39,7 @@ class ProposalCreator:
         self.n_test_post_nms = n_test_post_nms
         self.min_size = min_size
         self.strict = True
+        self._status = {}
 
     def counts(self):
         """(n_pre_nms, n_post_nms): only the literal "train" selects the train numbers."""
@@ -52,7 +53,12 @@ class ProposalCreator:
         if n_pre <= 0:
             n_pre = min(boxes.shape[1], 16384)
         counts, _, bs, _ = hip_ops.sort_topk_desc(keys, boxes, n_pre)
-        _, rois, _, status = hip_ops.nms_sorted(bs, counts, self.nms_iou, n_post)
+        # sticky device-side error word: allocated (zeroed) once per device, only ever OR-ed into by the NMS kernel,
+        # cleared by raise_if_error() - no per-forward memset launch
+        status = self._status.get(boxes.device)
+        if status is None:
+            status = self._status[boxes.device] = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
+        _, rois, _, status = hip_ops.nms_sorted(bs, counts, self.nms_iou, n_post, status=status)
         self.last_status = status
         if self.strict if strict is None else strict:
             self.raise_if_error()
@@ -61,6 +67,7 @@ class ProposalCreator:
     def raise_if_error(self):
         st = getattr(self, "last_status", None)
         if st is not None and int(st.item()) & 1:
+            st.zero_()
             raise IndexError("proposal padding needs more candidates than survive the min-size filter "
                              "(the reference raises IndexError at nets/rpn.py:69)")
 
