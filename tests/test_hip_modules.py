@@ -266,6 +266,24 @@ def test_forward_modes_surface(dev, synth):
         assert det.shape == (1, 300, 6)
 
 
+def test_batches_beyond_the_32bit_offset_range_are_cut_into_image_groups(dev, monkeypatch):
+    """The conv kernel uses 32-bit byte offsets; Plan.conv cuts a batch whose tensors exceed the limit into image
+    groups.  Forced here with a tiny limit: the grouped plan must reproduce the ungrouped result (to f32 summation-
+    order noise: the K-slice schedule is chosen per launch size)."""
+    from two_stage_object_detection_amd.engine import Plan
+    from two_stage_object_detection_amd.models.resnet import ResNet, Bottleneck
+    torch.manual_seed(4)
+    m = ResNet(Bottleneck, [1, 1, 1, 1], include_top=False).eval().to(dev)
+    x = _img((5, 3, 96, 128)).to(dev)
+    with torch.inference_mode():
+        ref = m(x).clone()
+        monkeypatch.setattr(Plan, "MAX_TENSOR_BYTES", 2 * 48 * 64 * 64 * 4 + 1)     # ~2 images of the stem output
+        m.invalidate_packed()
+        got = m(x)
+        assert len(m._plan_for(x).conv_steps) > 20          # really grouped
+    _feat_close(got.cpu(), ref.cpu(), rel=5e-6)
+
+
 def test_forwards_in_flight_on_several_streams(dev, synth):
     """Request-level pipelining (bench.py --in-flight): graphs of different slots replayed concurrently on separate HIP
     streams, each with its own input, must reproduce the serial results bit for bit (no shared scratch or buffers)."""

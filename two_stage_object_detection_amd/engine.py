@@ -119,12 +119,25 @@ class Plan:
         self.keep.extend(keep)
         return self.steps[-1]
 
+    # the conv kernel addresses every tensor through 32-bit byte offsets (buffer descriptors): one launch may
+    # touch at most this many bytes of any single tensor; larger batches are cut into image groups
+    MAX_TENSOR_BYTES = 0xF0000000
+
     def conv(self, pc: PackedConv, x: torch.Tensor, out: torch.Tensor, *, segs=None, out_off=0, residual=None,
              name="conv", tile=0, split_k=0):
         """x [N,H,W,P] -> out [N,OH,OW,Pout] (channel slice [out_off, out_off+Cout))."""
         N, H, W, P = x.shape
         OH, OW = pc.out_hw(H, W)
         assert tuple(out.shape[:3]) == (N, OH, OW), (out.shape, (N, OH, OW))
+        per_img = max(H * W * P, OH * OW * out.shape[3], 0 if residual is None else OH * OW * residual.shape[3]) * 4
+        if N > 1 and per_img * N >= self.MAX_TENSOR_BYTES:
+            group = max(1, self.MAX_TENSOR_BYTES // per_img)
+            for n0 in range(0, N, group):
+                n1 = min(N, n0 + group)
+                self.conv(pc, x[n0:n1], out[n0:n1], segs=segs, out_off=out_off,
+                          residual=None if residual is None else residual[n0:n1], name=f"{name}[{n0}:{n1}]", tile=tile,
+                          split_k=split_k)
+            return out
         segs = [(0, pc.cin)] if segs is None else _merge_adjacent(segs)
         d = make_conv_desc(N=N, H=H, W=W, in_pitch=P, segs=segs, Cout=pc.cout, out_pitch=out.shape[3], out_off=out_off,
                            KH=pc.kh, KW=pc.kw, stride=pc.stride, pad_h=pc.pad, pad_w=pc.pad, OH=OH, OW=OW, act=pc.act,
