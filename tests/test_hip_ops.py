@@ -229,7 +229,8 @@ def test_rpn_decode(ops, dev, B, Hf, Wf, stride):
     assert n_border <= 2
 
 
-@pytest.mark.parametrize("B,n,n_pre", [(1, 9450, 3000), (2, 37800, 3000), (1, 37800, 12000), (3, 500, 3000), (2, 4096, 64)])
+@pytest.mark.parametrize("B,n,n_pre", [(1, 9450, 3000), (2, 37800, 3000), (1, 37800, 12000), (3, 500, 3000), (2, 4096, 64),
+                                      (1, 9450, 2000), (2, 20000, 6000), (1, 70000, 16384)])
 def test_sort_topk_exact(ops, dev, B, n, n_pre):
     g = torch.Generator().manual_seed(13)
     keys = torch.rand(B, n, generator=g)

@@ -7,7 +7,8 @@
 //   2. 4x8-bit MSB-first radix select of the n_sel-th smallest d (histograms in LDS),
 //   3. compaction of every d < T plus the first `need` entries with d == T in index order
 //      (that is the stable tie rule: lower index first),
-//   4. bitonic sort of the <= n_pre composite keys (d << 32 | index) in LDS,
+//   4. bitonic sort of the <= n_pre composite keys (d << 32 | index): registers + lane shuffles, LDS only for the
+//      cross-wave distances,
 //   5. gather boxes / keys in sorted order.
 // Integer/index work: bit-exact against the oracle by construction.  No MFMA.
 #include "tsod_internal.h"
@@ -23,6 +24,68 @@ __device__ __forceinline__ unsigned desc_key(float f) {
     unsigned u = __float_as_uint(f);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending-orderable
     return ~u;                                        // descending-orderable
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int lane_mask) {
+    const unsigned lo = __shfl_xor((unsigned)v, lane_mask);
+    const unsigned hi = __shfl_xor((unsigned)(v >> 32), lane_mask);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Ascending bitonic sort of S = E * kThreads composite keys held in LDS.  Thread t keeps elements [t*E, t*E+E) in
+// registers for the whole network: exchanges at distance < E are register swaps, at distance < 64*E lane shuffles
+// inside the wave, and only the few longest distances of each merge go through LDS (two barriers each).  For
+// S = 4096 that is 10 LDS stages out of 78.
+template <int E>
+__device__ __noinline__ void block_bitonic(unsigned long long *sm, int tid) {
+    constexpr int S = E * kThreads;
+    constexpr int LOG_E = E == 1 ? 0 : E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : 4;
+    unsigned long long v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = sm[tid * E + e];
+    for (int kk = 2; kk <= S; kk <<= 1) {
+        int j = kk >> 1;
+        for (; j >= 64 * E; j >>= 1) {            // partner lives in another wave
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e) sm[tid * E + e] = v[e];
+            __syncthreads();
+            const int pbase = (tid ^ (j >> LOG_E)) * E;
+            const bool is_lo = ((tid * E) & j) == 0;
+            const bool up = ((tid * E) & kk) == 0;       // kk > j >= E: the same for all E elements
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const unsigned long long o = sm[pbase + e];
+                const bool take_min = is_lo == up;
+                v[e] = take_min ? (o < v[e] ? o : v[e]) : (o > v[e] ? o : v[e]);
+            }
+        }
+        for (; j >= E; j >>= 1) {                 // partner is a lane of this wave
+            const bool is_lo = ((tid * E) & j) == 0;
+            const bool up = ((tid * E) & kk) == 0;      // j >= E implies kk > E
+            const bool take_min = is_lo == up;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const unsigned long long o = shfl_xor_u64(v[e], j >> LOG_E);
+                v[e] = take_min ? (o < v[e] ? o : v[e]) : (o > v[e] ? o : v[e]);
+            }
+        }
+#pragma unroll
+        for (int jj = E / 2; jj > 0; jj >>= 1) {  // partner is another register of this thread
+            if (jj > (kk >> 1)) continue;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (e & jj) continue;
+                const bool up = ((tid * E + e) & kk) == 0;
+                const unsigned long long a = v[e], c = v[e | jj];
+                if ((a > c) == up) { v[e] = c; v[e | jj] = a; }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) sm[tid * E + e] = v[e];
+    __syncthreads();
 }
 
 template <int KPT>  // keys per thread held in registers: every pass after the first runs without touching memory
@@ -77,20 +140,19 @@ sort_topk_kernel(const float *__restrict__ keys, const float *__restrict__ boxes
                 const unsigned d = dk[q];
                 bool pending = i < n && (d & mask) == prefix;
                 const unsigned bin = (d >> shift) & 255u;
-                // scores share sign/exponent bits, so the leading digits put most of a wave into a handful of
-                // bins: count each of the first few distinct bins once per wave (ballot + popcount, one LDS
-                // atomic) instead of 64 serialised same-address atomics; stragglers use plain atomics
-                for (int round = 0; round < 4; ++round) {
-                    const unsigned long long live = __ballot(pending);
-                    if (live == 0ull) break;
+                // scores share sign/exponent bits, so a leading digit can put a whole wave into one bin: count the
+                // first pending lane's bin once per wave (ballot + popcount, one LDS atomic) instead of up to 64
+                // serialised same-address atomics; lanes in other bins use plain LDS atomics (spread digits rarely
+                // collide).  The lane index comes from a ballot, so it is wave-uniform: v_readlane, no LDS shuffle.
+                const unsigned long long live = __ballot(pending);
+                if (live != 0ull) {
                     const int leader = __ffsll((long long)live) - 1;
-                    const unsigned lb = __shfl(bin, leader);
+                    const unsigned lb = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
                     const bool same = pending && bin == lb;
                     const unsigned long long grp = __ballot(same);
                     if (lane == leader) atomicAdd(&hist[lb], (unsigned)__popcll(grp));
-                    pending = pending && !same;
+                    if (pending && !same) atomicAdd(&hist[bin], 1u);
                 }
-                if (pending) atomicAdd(&hist[bin], 1u);
             }
             __syncthreads();
             // inclusive scan of the 256 bins by the first 4 waves: shuffles inside a wave, wave totals through LDS
@@ -157,24 +219,16 @@ sort_topk_kernel(const float *__restrict__ keys, const float *__restrict__ boxes
                 __syncthreads();
             }
         }
-        int Ps = 2;                       // sort only the power of two that covers the selection
-        while (Ps < n_sel) Ps <<= 1;
-        for (int i = n_sel + tid; i < Ps; i += kThreads) sm[i] = ~0ull;
+        int S = kThreads;                 // sort only the power of two that covers the selection (>= one key per thread)
+        while (S < n_sel) S <<= 1;
+        for (int i = n_sel + tid; i < S; i += kThreads) sm[i] = ~0ull;
         __syncthreads();
-
-        // ---- bitonic sort, ascending in the composite key (j = 2^lj: shifts, no integer division).
-        for (int kk = 2; kk <= Ps; kk <<= 1) {
-            for (int lj = 31 - __clz(kk >> 1); lj >= 0; --lj) {
-                const int j = 1 << lj;
-                for (int t = tid; t < (Ps >> 1); t += kThreads) {
-                    const int lo = ((t >> lj) << (lj + 1)) | (t & (j - 1));
-                    const int hi = lo + j;
-                    const unsigned long long a = sm[lo], c = sm[hi];
-                    const bool up = (lo & kk) == 0;
-                    if ((a > c) == up) { sm[lo] = c; sm[hi] = a; }
-                }
-                __syncthreads();
-            }
+        switch (S / kThreads) {
+            case 1: block_bitonic<1>(sm, tid); break;
+            case 2: block_bitonic<2>(sm, tid); break;
+            case 4: block_bitonic<4>(sm, tid); break;
+            case 8: block_bitonic<8>(sm, tid); break;
+            default: block_bitonic<16>(sm, tid); break;
         }
     }
 
@@ -203,7 +257,7 @@ extern "C" int tsod_sort_topk_desc_f32(const float *keys, const float *boxes, in
     TSOD_REQUIRE(boxes_out == nullptr || boxes != nullptr, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE((boxes == nullptr || tsod_aligned16(boxes)) && (boxes_out == nullptr || tsod_aligned16(boxes_out)),
                  TSOD_ERR_ALIGNMENT);
-    int P = 2;
+    int P = kThreads;                       // the sort network runs on >= one key per thread
     while (P < n_pre) P <<= 1;
     const size_t lds = (size_t)P * sizeof(unsigned long long);
 #define TSOD_SORT(KPT)                                                                                                 \
