@@ -16,6 +16,8 @@ every rank processes its own batch; value = images of all ranks / max-over-ranks
 The JSON line also carries
   roofline     : f32-MFMA roofline of the dominant kernel family (conv_igemm_kernel, all launches of one
                  forward): algorithmic FLOPs / HIP-event time of those launches, vs 157.3 TFLOP/s.
+                 roofline.traffic = HBM bytes per conv launch from the FETCH_SIZE / WRITE_SIZE counters, collected
+                 by two short `rocprofv3 --pmc` child runs of this script (rank 0, N=1; --no-pmc skips them).
   cpu_baseline : the CPU oracle (torch CPU ops + C nms/roi_pool restatement of the reference's path)
                  timed on this box's host cores on the same workload (rank 0, N=1 only).
 """
@@ -55,6 +57,8 @@ def parse():
     ap.add_argument("--tiles-file", default=None, help="JSON cache of autotuned (tile, split) choices: loaded if present, "
                                                        "else written after autotuning (keeps profiler runs free of tuning launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs behind roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the real path) | gloo (rehearsal of "
@@ -98,6 +102,83 @@ def cpu_baseline(sd, backbone, x_cpu, reps):
             "seconds_per_forward": med}
 
 
+def conv_algorithmic_bytes(plan):
+    """Input + output + weights (+ residual) of every conv launch, each counted once (f32)."""
+    tot = 0
+    for st in plan.conv_steps:
+        d = st.desc
+        cin = sum(d.seg_len[i] for i in range(d.n_seg))
+        tot += 4 * (d.N * d.H * d.W * cin + d.N * d.OH * d.OW * d.Cout + d.Cout * d.KH * d.KW * cin)
+        if d.res_pitch > 0:
+            tot += 4 * d.N * d.OH * d.OW * d.Cout
+    return tot
+
+
+def pmc_child(args, dev):
+    """Body of the `rocprofv3 --pmc` child: build the plan with the parent's tile choices, then issue the conv
+    launches of one forward twice, eagerly, so that every dispatch carries its own counter sample."""
+    from two_stage_object_detection_amd._ffi import lib, stream_ptr
+    from two_stage_object_detection_amd.testing import synthetic_detector
+    model, _ = synthetic_detector(args.backbone, num_classes=args.num_classes, seed=0)
+    model = model.to(dev).eval()
+    x = torch.rand(args.batch, 3, args.height, args.width, generator=torch.Generator().manual_seed(1234)).to(dev)
+    with torch.inference_mode():
+        plan = model.extractor._plan_for(x)                 # packs weights, launches no conv
+        if args.tiles_file and os.path.exists(args.tiles_file):
+            plan.import_tiles(json.load(open(args.tiles_file)))
+        torch.cuda.synchronize()
+        L, s = lib(), stream_ptr()
+        for _ in range(2):                                  # pass 1 warms caches / code objects, pass 2 is the sample
+            for st in plan.conv_steps:
+                L.tsod_conv2d_f32(*st.args, s)
+        torch.cuda.synchronize()
+
+
+def pmc_traffic(args, plan, n_launches):
+    """HBM bytes per conv launch from rocprofv3's FETCH_SIZE / WRITE_SIZE (KiB; separate passes: both do not fit
+    the TCC counter budget at once).  gfx950 tallies a wide coalesced read at half its size, so reads are doubled
+    (MI355X_MICROARCH.md, HBM section).  Returns (bytes_per_launch or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    work = tempfile.mkdtemp(prefix="tsod_pmc_", dir="/tmp")
+    try:
+        tiles = os.path.join(work, "tiles.json")
+        json.dump(plan.export_tiles(), open(tiles, "w"))
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        sums = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--tiles-file", tiles,
+                   "--backbone", args.backbone, "--batch", str(args.batch), "--height", str(args.height),
+                   "--width", str(args.width), "--num-classes", str(args.num_classes)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+            files = glob.glob(os.path.join(out, "*", "*counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            rows = [(int(q["Dispatch_Id"]), float(q["Counter_Value"])) for q in csv.DictReader(open(files[0]))
+                    if q["Counter_Name"] == counter and ("conv_igemm_kernel" in q["Kernel_Name"]
+                                                         or "conv_reduce_kernel" in q["Kernel_Name"])]
+            rows.sort()
+            if not rows or len(rows) % 2:
+                return None, f"unexpected dispatch count {len(rows)} in the {counter} pass"
+            sums[counter] = sum(v for _, v in rows[len(rows) // 2:])          # the second of the two conv passes
+        total = (2.0 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"]) * 1024.0
+        return total / n_launches, None
+    except Exception as e:                                                     # noqa: BLE001 - never fail the bench on this leg
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -117,6 +198,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+
+    if args.pmc_child:
+        pmc_child(args, dev)
+        return
 
     from two_stage_object_detection_amd import hip_ops
     from two_stage_object_detection_amd.dist import all_gather_detections
@@ -217,6 +302,7 @@ def main():
         value = n_gpus * B * args.steps / elapsed
         conv_total_ms = sum(conv_ms)
         achieved = conv_flops / (conv_total_ms * 1e-3) / 1e12
+        traffic, traffic_note = (None, "skipped") if (n_gpus > 1 or args.no_pmc) else pmc_traffic(args, plan, len(conv_ms))
         line = {
             "metric": "images/sec Faster R-CNN ResNet-50 @800x1333" if args.backbone == "resnet50"
                       else f"images/sec Faster R-CNN {args.backbone} @{args.height}x{args.width}",
@@ -230,7 +316,11 @@ def main():
                        "steps_in_flight": 1 if args.no_graph else max(1, args.in_flight),
                        "collective": None if n_gpus == 1 else f"all_gather_into_tensor [{n_gpus * B},300,6] f32 ({args.dist_backend})"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None if traffic is None else round(traffic),
+                         "traffic_unit": "HBM bytes per conv launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 / launches, incl. the "
+                                         "K-slice reduce kernels" + ("" if traffic_note is None else f" [{traffic_note}]"),
+                         "algorithmic_bytes_per_launch": round(conv_algorithmic_bytes(plan) / len(conv_ms)),
                          "kernel": f"conv_igemm_kernel (f32 MFMA implicit GEMM), {len(conv_ms)} launches per forward",
                          "flops_per_forward": conv_flops, "kernel_ms_per_forward": round(conv_total_ms, 4),
                          "share_of_single_stream_forward": None if latency_ms is None else round(conv_total_ms / latency_ms, 4)},
