@@ -22,7 +22,7 @@ def load(d):
 sq, dsq = load(sys.argv[1]); fe, dfe = load(sys.argv[2]); wr, dwr = load(sys.argv[3])
 print("# Round 1 - PMC counters, `bench.py --no-graph` (B=1, 3x800x1333, ResNet-50), rocprofv3 --pmc, separate passes\n")
 print("Per dispatch, averaged over the second half of each kernel's dispatches (the timed steps; the first half contains")
-print("plan building). `FETCH_SIZE` / `WRITE_SIZE` are in KB; on gfx950 `FETCH_SIZE` under-reports wide coalesced reads by 2x")
+print("plan building). `FETCH_SIZE` / `WRITE_SIZE` are in KiB; on gfx950 `FETCH_SIZE` under-reports wide coalesced reads by 2x")
 print("(MI355X_MICROARCH.md, HBM section), so HBM read bytes = 2 x FETCH_SIZE.  Commands: profiles/README.md.\n")
 g = [c.get('GRBM_GUI_ACTIVE') for k in fe if 'conv_igemm' in k for _, c in fe[k].items() if c.get('GRBM_GUI_ACTIVE')]
 d = [dfe[i] for k in fe if 'conv_igemm' in k for i, c in fe[k].items() if c.get('GRBM_GUI_ACTIVE')]
@@ -50,7 +50,7 @@ for k in sorted(sq):
 print(f"\nAll conv_igemm dispatches together: MFMA pipes busy **{100 * tot_mf / tot_cyc:.1f}%** of the time these kernels run (this counts the")
 print("zero-weight padding work of the 7x8x4 stem and of partial edge tiles, which the algorithmic TFLOP/s in bench.py does not).\n")
 print("## HBM traffic of the memory-bound kernels (passes 2 and 3: FETCH_SIZE, WRITE_SIZE)\n")
-print("| kernel | avg us | FETCH_SIZE KB | WRITE_SIZE KB | HBM MB = (2*FETCH+WRITE)/1000 | achieved GB/s (PMC bytes / time) | algorithmic MB (DESIGN.md section 4) |")
+print("| kernel | avg us | FETCH_SIZE KB | WRITE_SIZE KB | HBM MB = (2*FETCH+WRITE)*1024/1e6 | achieved GB/s (PMC bytes / time) | algorithmic MB (DESIGN.md section 4) |")
 print("|---|---:|---:|---:|---:|---:|---:|")
 alg = {'maxpool3x3s2_kernel': 85.4, 'nchw_to_nhwc_small_kernel': 29.9, 'rpn_decode_kernel': 0.42, 'roi_pool_avg_kernel': 11.1,
        'nms_mask_kernel': 1.18, 'nms_scan_kernel<1>': 1.13, 'sort_topk_kernel<10>': 0.11, 'detections_kernel': 0.5}
@@ -63,8 +63,39 @@ for k in ['nchw_to_nhwc_small_kernel', 'maxpool3x3s2_kernel', 'conv_reduce_kerne
     f = sum(c.get('FETCH_SIZE', 0) for _, c in ds) / n
     dw = list(wr[k].items()); dw = dw[len(dw) // 2:]
     w = sum(c.get('WRITE_SIZE', 0) for _, c in dw) / max(1, len(dw))
-    mb = (2 * f + w) / 1000.0
+    mb = (2 * f + w) * 1024 / 1e6
     a = alg.get(k)
     print(f"| `{k}` | {us:.1f} | {f:.0f} | {w:.0f} | {mb:.2f} | {mb * 1e6 / (us * 1e-6) / 1e9:.0f} | {'' if a is None else a} |")
 print(f"\nClock check: sum(GRBM_GUI_ACTIVE)/8/sum(duration) over the conv dispatches = {clock_meas / 1e9:.2f} GHz (this quotient reads high on")
 print("dispatches shorter than ~0.3 ms; the table uses min(measured, 2.4 GHz)): the chip holds its full clock under f32 MFMA load.")
+
+
+def last_forward(per):
+    """Counter sums per kernel family over the dispatches of the last forward (from the last NCHW->NHWC launch on)."""
+    start = max(int(i) for k in per if 'nchw_to_nhwc' in k for i in per[k])
+    out = collections.defaultdict(lambda: [0, 0.0])
+    for k in per:
+        fam = 'conv_igemm_kernel' if 'conv_igemm' in k else k
+        for i, c in per[k].items():
+            if int(i) >= start:
+                out[fam][0] += 1
+                out[fam][1] += sum(v for n, v in c.items() if n in ('FETCH_SIZE', 'WRITE_SIZE'))
+    return out
+
+lf, lw = last_forward(fe), last_forward(wr)
+print("\n## HBM traffic of the conv GEMMs in one forward (last forward of passes 2 and 3)\n")
+print("| kernel family | dispatches | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM MB = (2*FETCH+WRITE)*1024/1e6 |")
+print("|---|---:|---:|---:|---:|")
+tot = 0.0
+for fam in ('conv_igemm_kernel', 'conv_reduce_kernel'):
+    if fam not in lf:
+        continue
+    mb = (2 * lf[fam][1] + lw[fam][1]) * 1024 / 1e6
+    tot += mb
+    print(f"| `{fam}` | {lf[fam][0]} | {lf[fam][1]:.0f} | {lw[fam][1]:.0f} | {mb:.1f} |")
+print(f"\nTogether {tot / 1e3:.2f} GB per forward (B=1, all 57 GEMM launches incl. RPN and head).  bench.py's `roofline.traffic` is the")
+print("same measurement made live (two `rocprofv3 --pmc` child passes) over the 53 trunk launches with that run's own tile")
+print("choices, per launch; `roofline.algorithmic_bytes_per_launch` is each layer's input + output + weights (+ residual) once.")
+print("The excess over the algorithmic bytes is (a) the K-slice partial slabs (written by the GEMM, read by the reduce kernel),")
+print("(b) the activation tile re-read by every output-channel tile of its row block once it has left the XCD's L2,")
+print("(c) the 7x8x4 stem reading its 4-channel input 7 times.  The trunk is matrix-pipe / latency bound at batch 1, not HBM bound.")
