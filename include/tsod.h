@@ -64,7 +64,8 @@ enum { TSOD_ACT_NONE = 0, TSOD_ACT_PRELU = 1, TSOD_ACT_RELU6 = 2, TSOD_ACT_RELU 
 enum { TSOD_TILE_AUTO = 0, TSOD_TILE_128x128 = 1, TSOD_TILE_128x64 = 2, TSOD_TILE_64x64 = 3, TSOD_TILE_64x128 = 4,
        TSOD_TILE_128x128_W8 = 5, TSOD_TILE_128x64_W8 = 6, TSOD_TILE_256x128_W8 = 7, TSOD_TILE_64x64_S1 = 8,
        TSOD_TILE_128x64_W8_S1 = 9, TSOD_TILE_64x64_S1_K64 = 10, TSOD_TILE_128x64_W8_S1_K64 = 11,
-       TSOD_TILE_64x64_W1_S1 = 12, TSOD_TILE_128x64_W2_S1 = 13, TSOD_TILE_COUNT = 14 };
+       TSOD_TILE_64x64_W1_S1 = 12, TSOD_TILE_128x64_W2_S1 = 13, TSOD_TILE_128x64_S1 = 14, TSOD_TILE_64x128_S1 = 15,
+       TSOD_TILE_COUNT = 16 };
 #define TSOD_MAX_SEGMENTS 16
 
 typedef struct tsod_conv2d_desc {

@@ -18,8 +18,8 @@ TSOD_MAX_SEGMENTS = 16
 ACT_NONE, ACT_PRELU, ACT_RELU6, ACT_RELU = 0, 1, 2, 3
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4
 TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "64x128", 5: "128x128w8", 6: "128x64w8", 7: "256x128w8",
-              8: "64x64s1", 9: "128x64w8s1", 10: "64x64s1k64", 11: "128x64w8s1k64", 12: "64x64w1s1", 13: "128x64w2s1"}
-TILE_IDS = tuple(range(1, 14))
+              8: "64x64s1", 9: "128x64w8s1", 10: "64x64s1k64", 11: "128x64w8s1k64", 12: "64x64w1s1", 13: "128x64w2s1", 14: "128x64s1", 15: "64x128s1"}
+TILE_IDS = tuple(range(1, 16))
 
 
 class TsodError(RuntimeError):

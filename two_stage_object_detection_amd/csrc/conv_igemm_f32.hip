@@ -447,7 +447,7 @@ const TileInfo kTiles[TSOD_TILE_COUNT] = {
     {0, 0, 0, 0, 0.f, 32},        {128, 128, 256, 2, 1.00f, 32}, {128, 64, 256, 2, 1.06f, 32}, {64, 64, 256, 4, 1.15f, 32},
     {64, 128, 256, 2, 1.06f, 32}, {128, 128, 512, 2, 1.00f, 32}, {128, 64, 512, 2, 1.06f, 32}, {256, 128, 512, 1, 0.98f, 32},
     {64, 64, 256, 6, 1.20f, 32},  {128, 64, 512, 3, 1.10f, 32},  {64, 64, 256, 4, 1.10f, 64},  {128, 64, 512, 2, 1.05f, 64},
-    {64, 64, 64, 8, 1.40f, 32},   {128, 64, 128, 4, 1.35f, 32}};
+    {64, 64, 64, 8, 1.40f, 32},   {128, 64, 128, 4, 1.35f, 32}, {128, 64, 256, 4, 1.12f, 32}, {64, 128, 256, 4, 1.12f, 32}};
 
 int validate(const tsod_conv2d_desc *d) {
     TSOD_REQUIRE(d != nullptr, TSOD_ERR_INVALID_ARG);
@@ -656,6 +656,8 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
         case TSOD_TILE_128x64_W8_S1_K64: launch_tile<128, 64, 32, 32, 4, 1, 64>(p, sc.grid, s); break;
         case TSOD_TILE_64x64_W1_S1: launch_tile<64, 64, 64, 64, 2, 1>(p, sc.grid, s); break;
         case TSOD_TILE_128x64_W2_S1: launch_tile<128, 64, 64, 64, 2, 1>(p, sc.grid, s); break;
+        case TSOD_TILE_128x64_S1: launch_tile<128, 64, 64, 32, 4, 1>(p, sc.grid, s); break;
+        case TSOD_TILE_64x128_S1: launch_tile<64, 128, 32, 64, 4, 1>(p, sc.grid, s); break;
         default: launch_tile<64, 64, 32, 32, 4>(p, sc.grid, s); break;
     }
     if (sc.rem_tiles > 0)
