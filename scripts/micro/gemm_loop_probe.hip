@@ -3,6 +3,7 @@
 //   bit 0: no global loads in the loop (registers keep the first K-step)
 //   bit 1: no LDS writes in the loop (LDS keeps the first K-step; the barrier pair goes too)
 //   bit 2: no LDS fragment reads in the loop (fragments stay in registers)
+//   bit 3: no barriers around the LDS writes (racy on purpose: prices the barriers alone)
 // WAVES = 1 (one wave owns the 64x64 tile) or 4 (four waves, 32x32 each).  Results are meaningless with a switch on;
 // only the timing matters.  Build: hipcc -O3 --offload-arch=gfx950 gemm_loop_probe.hip -o probe
 #include <hip/hip_runtime.h>
@@ -93,9 +94,9 @@ probe(const float *__restrict__ A, const float *__restrict__ B, float *__restric
                 }
         }
         if (!(FLAGS & 2)) {
-            __syncthreads();
+            if (!(FLAGS & 8)) __syncthreads();
             if (more) store_lds();
-            __syncthreads();
+            if (!(FLAGS & 8)) __syncthreads();
         }
     }
     // plain column-per-lane store (not part of the question)
@@ -209,8 +210,8 @@ void run(const float *A, const float *B, float *C, int M, int N, int K) {
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     ms /= 5;
-    printf("waves %d  no-global %d no-ldswrite %d no-ldsread %d : %7.3f ms  %6.1f TF/s\n", WAVES, FLAGS & 1, (FLAGS >> 1) & 1,
-           (FLAGS >> 2) & 1, ms, 2.0 * M * N * K / ms / 1e9);
+    printf("waves %d  no-global %d no-ldswrite %d no-ldsread %d no-barrier %d : %7.3f ms  %6.1f TF/s\n", WAVES, FLAGS & 1,
+           (FLAGS >> 1) & 1, (FLAGS >> 2) & 1, (FLAGS >> 3) & 1, ms, 2.0 * M * N * K / ms / 1e9);
 }
 
 int main(int argc, char **argv) {
@@ -226,7 +227,7 @@ int main(int argc, char **argv) {
     run<1, 0>(A, B, C, M, N, K); run<1, 1>(A, B, C, M, N, K); run<1, 3>(A, B, C, M, N, K); run<1, 7>(A, B, C, M, N, K);
     run<1, 4>(A, B, C, M, N, K); run<1, 2>(A, B, C, M, N, K);
     run<4, 0>(A, B, C, M, N, K); run<4, 1>(A, B, C, M, N, K); run<4, 3>(A, B, C, M, N, K); run<4, 7>(A, B, C, M, N, K);
-    run<4, 4>(A, B, C, M, N, K); run<4, 2>(A, B, C, M, N, K);
+    run<4, 4>(A, B, C, M, N, K); run<4, 2>(A, B, C, M, N, K); run<4, 9>(A, B, C, M, N, K); run<4, 8>(A, B, C, M, N, K);
     run_glds<2>(A, B, C, M, N, K); run_glds<3>(A, B, C, M, N, K); run_glds<4>(A, B, C, M, N, K);
     // the DMA path must reproduce the register-staged result bit for bit (same k order per MFMA chain)
     std::vector<float> c0((size_t)M * N), c1((size_t)M * N);
