@@ -228,6 +228,26 @@ int tsod_roi_pool_avg_f32(const float *feat, int32_t B, int32_t Hf, int32_t Wf, 
 int tsod_detections_f32(const float *cls_locs, const float *scores, const float *rois, int32_t K,
                         int32_t n_class, float *det, tsod_stream_t stream);
 
+/* ---- inference-time filtering of the records (the step after the path) ------------------
+ * The reference's demo keeps `nms(boxes_pred, labels_score_pred, iou_threshold=0.1)` over the records of an
+ * image, class-agnostic, no score threshold (multi_inference.py:84).  These three calls are that step with the
+ * two switches a deployment adds (score threshold / background class, per-class suppression):
+ *   1. tsod_detection_keys_f32   keys[t] = score if (score >= score_thresh and class != background_class) else -inf
+ *                                (background_class < 0: no class is dropped; NaN scores are dropped)
+ *   2. tsod_sort_topk_desc_f32(keys, NULL, B, R, R, counts, idx, NULL, NULL)   stable descending order, -inf rows dropped
+ *      tsod_gather_rows_f32      det_sorted[b][r][:] = det[b][idx[b][r]][:]  (zero rows where idx < 0)
+ *   3. tsod_detection_nms_f32    greedy NMS over det_sorted [B][R][6] (columns 0-3 box, 5 class), suppress j when
+ *                                IoU(i,j) > thr (strict) and - with per_class != 0 - class_i == class_j.
+ *                                keep_idx [B][R] int32: surviving rows of det_sorted in score order, -1 after n_kept[b].
+ *                                workspace: tsod_nms_workspace_bytes(B, R).  R <= 8192. */
+int tsod_detection_keys_f32(const float *det, int64_t n, float score_thresh, int32_t background_class, float *keys,
+                            tsod_stream_t stream);
+int tsod_gather_rows_f32(const float *src, const int32_t *idx, int32_t B, int32_t n, int32_t m, int32_t C, float *out,
+                         tsod_stream_t stream);
+int tsod_detection_nms_f32(const float *det_sorted, const int32_t *counts, int32_t B, int32_t R, float iou_thr,
+                           int32_t per_class, int32_t *keep_idx, int32_t *n_kept, void *workspace,
+                           size_t workspace_bytes, tsod_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

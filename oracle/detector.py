@@ -63,13 +63,31 @@ def detections_from_outputs(roi_cls_locs, roi_scores, rois):
     return torch.cat([boxes, score.unsqueeze(-1), cls.to(boxes.dtype).unsqueeze(-1)], dim=-1)
 
 
-def postprocess(det, iou_threshold=0.1):
+def postprocess(det, iou_threshold=0.1, score_thresh=None, per_class=False, background_class=-1):
     """multi_inference.py:80-87 for a batch of detection records [B,R,6]: per image
-    ``keep = nms(boxes_pred, labels_score_pred, iou_threshold)`` (class-agnostic).  Returns a list of kept
-    record tensors, each in descending-score order (what ``boxes_pred[keep]`` etc. are in the reference)."""
+    ``keep = nms(boxes_pred, labels_score_pred, iou_threshold)`` (class-agnostic, no score threshold: the defaults).
+    ``score_thresh`` / ``background_class`` drop records first; ``per_class`` runs the same nms once per class and
+    merges the survivors by score (what torchvision's ``batched_nms`` computes, without its coordinate-offset
+    shortcut).  Returns a list of kept record tensors, each in descending-score order (stable: ties keep RoI order)."""
     from .box import nms
     out = []
     for d in det:
-        keep = nms(d[:, :4], d[:, 4], iou_threshold)
+        ok = torch.ones(d.shape[0], dtype=torch.bool)
+        if score_thresh is not None:
+            ok &= d[:, 4] >= score_thresh
+        ok &= ~torch.isnan(d[:, 4]) & (d[:, 4] > float("-inf"))
+        if background_class >= 0:
+            ok &= d[:, 5] != float(background_class)
+        d = d[ok]
+        order = torch.sort(d[:, 4], descending=True, stable=True).indices
+        d = d[order]
+        if not per_class:
+            keep = nms(d[:, :4], d[:, 4], iou_threshold)
+        else:
+            keeps = []
+            for c in torch.unique(d[:, 5]).tolist():
+                rows = torch.nonzero(d[:, 5] == c).squeeze(1)
+                keeps.append(rows[nms(d[rows, :4], d[rows, 4], iou_threshold)])
+            keep = torch.sort(torch.cat(keeps)).values if keeps else torch.zeros(0, dtype=torch.long)
         out.append(d[keep])
     return out

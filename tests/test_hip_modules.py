@@ -233,21 +233,53 @@ def test_odd_geometry_and_ragged_batch(dev, synth):
     assert rep["ok"], rep
 
 
-def test_postprocess_nms_like_the_demo_script(dev, synth):
-    """the step after the path - multi_inference.py:84's class-agnostic NMS(0.1) over the records."""
+def _overlapping_records(seed, B=2, R=300, n_class=21):
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand(B, R, 2, generator=g) * 300
+    score = torch.randn(B, R, 1, generator=g)
+    score = (score * 8).round() / 8                                  # exact score ties -> the stable rule matters
+    return torch.cat([xy, xy + torch.rand(B, R, 2, generator=g) * 200 + 5, score,
+                      torch.randint(0, n_class, (B, R, 1), generator=g).float()], dim=-1)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(per_class=True), dict(score_thresh=0.25), dict(background_class=0),
+                                dict(per_class=True, score_thresh=-0.5, background_class=3), dict(score_thresh=1e9)])
+def test_postprocess_nms_like_the_demo_script(dev, synth, kw):
+    """the step after the path - multi_inference.py:84's class-agnostic NMS(0.1) over the records
+    (the defaults), plus the score-threshold / background / per-class switches.  Index work: bit-exact."""
     model, sd = synth("resnet50")
-    g = torch.Generator().manual_seed(31)
     # records with heavy overlap so that NMS at 0.1 really prunes; fed to both sides (stage-wise)
-    xy = torch.rand(2, 300, 2, generator=g) * 300
-    det = torch.cat([xy, xy + torch.rand(2, 300, 2, generator=g) * 200 + 5, torch.randn(2, 300, 1, generator=g),
-                     torch.randint(0, 21, (2, 300, 1), generator=g).float()], dim=-1)
-    ref = oracle.postprocess(det, 0.1)
-    det_sorted, keep, n_kept = model.postprocess(det.to(dev), 0.1)
+    det = _overlapping_records(31)
+    det[1, 5, 4] = float("nan")                                      # a NaN score is dropped, not sorted somewhere
+    ref = oracle.postprocess(det, 0.1, **kw)
+    det_sorted, keep, n_kept = model.postprocess(det.to(dev), 0.1, **kw)
     for b in range(2):
         k = int(n_kept[b])
-        assert k == ref[b].shape[0] and 0 < k < 300
+        assert k == ref[b].shape[0] and k < 300
+        assert (k > 0) == (kw.get("score_thresh", 0) < 1e8)
         got = det_sorted[b][keep[b, :k].long()].cpu()
         assert torch.equal(got, ref[b])
+        assert (keep[b, k:] == -1).all()
+
+
+def test_per_class_nms_keeps_more_than_class_agnostic(dev, synth):
+    model, _ = synth("resnet50")
+    det = _overlapping_records(32).to(dev)
+    _, _, n_any = model.postprocess(det, 0.1)
+    _, _, n_cls = model.postprocess(det, 0.1, per_class=True)
+    assert (n_cls > n_any).all()
+
+
+def test_predict_is_forward_plus_records_plus_filter(dev, synth):
+    model, sd = synth("resnet50")
+    x = _img((2, 3, 224, 320), seed=12)
+    with torch.inference_mode():
+        det = model.detections(x.to(dev)).cpu()
+        got = model.predict(x.to(dev), per_class=True, score_thresh=float(det[..., 4].median()))
+    ref = oracle.postprocess(det, 0.1, score_thresh=float(det[..., 4].median()), per_class=True)
+    assert len(got) == 2
+    for b in range(2):
+        assert torch.equal(got[b].cpu(), ref[b])
 
 
 def test_forward_modes_surface(dev, synth):

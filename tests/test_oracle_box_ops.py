@@ -117,3 +117,29 @@ def test_proposal_layer_small():
     # fewer candidates than the pad needs -> IndexError like the reference (Q4)
     with pytest.raises(IndexError):
         oracle.proposal_layer(loc[:50], score[:50], anchor[:50], (3, 192, 224))
+
+
+def test_postprocess_per_class_equals_one_nms_per_class():
+    """oracle.postprocess(per_class=True) against the definition: filter, sort, nms inside each class, merge by score."""
+    import oracle
+    g = torch.Generator().manual_seed(5)
+    xy = torch.rand(1, 120, 2, generator=g) * 100
+    det = torch.cat([xy, xy + torch.rand(1, 120, 2, generator=g) * 80 + 2, torch.randn(1, 120, 1, generator=g),
+                     torch.randint(0, 4, (1, 120, 1), generator=g).float()], dim=-1)
+    out = oracle.postprocess(det, 0.3, score_thresh=-0.2, per_class=True, background_class=0)[0]
+    d = det[0]
+    d = d[(d[:, 4] >= -0.2) & (d[:, 5] != 0)]
+    expect = []
+    for c in (1.0, 2.0, 3.0):
+        dc = d[d[:, 5] == c]
+        keep = nms_python(dc[:, :4].numpy(), dc[:, 4].numpy(), 0.3)
+        expect.append(dc[keep])
+    expect = torch.cat(expect)
+    expect = expect[torch.sort(expect[:, 4], descending=True, stable=True).indices]
+    assert out.shape == expect.shape and out.shape[0] > 3
+    assert torch.equal(torch.sort(out[:, 4], descending=True).values, expect[:, 4])
+    assert {tuple(r.tolist()) for r in out} == {tuple(r.tolist()) for r in expect}
+    # class-agnostic default = one nms over everything
+    out0 = oracle.postprocess(det, 0.3)[0]
+    keep0 = nms_python(det[0, :, :4].numpy(), det[0, :, 4].numpy(), 0.3)
+    assert torch.equal(out0, det[0][keep0])

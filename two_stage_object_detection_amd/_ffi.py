@@ -75,6 +75,10 @@ _SIGNATURES = {
     "tsod_roi_pool_avg_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
                                       c_float, c_float, c_float, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "tsod_detections_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "tsod_detection_keys_f32": (c_int, [c_void_p, c_int64, c_float, c_int32, c_void_p, c_void_p]),
+    "tsod_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "tsod_detection_nms_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p, c_void_p, c_void_p,
+                                       c_size_t, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -31,27 +31,38 @@ __device__ __forceinline__ float iou_nms(const float4 a, const float4 b) {
     return inter / (area_a + area_b - inter);
 }
 
+// Row r of a [n][stride] f32 table as a box: stride 4 is the aligned RPN layout, 6 the detection records.
+__device__ __forceinline__ float4 load_box(const float *__restrict__ base, int stride, int r) {
+    if (stride == 4) return reinterpret_cast<const float4 *>(base)[r];
+    const float *q = base + (long)r * stride;
+    return make_float4(q[0], q[1], q[2], q[3]);
+}
+
+// label_col >= 0: column of the row that holds the class; pairs of different classes never suppress each other.
 __global__ void __launch_bounds__(64)
-nms_mask_kernel(const float *__restrict__ boxes, const int *__restrict__ counts, int n_max, int words, float thr,
-                unsigned long long *__restrict__ mask) {
+nms_mask_kernel(const float *__restrict__ boxes, int stride, int label_col, const int *__restrict__ counts, int n_max,
+                int words, float thr, unsigned long long *__restrict__ mask) {
     const int cb = blockIdx.x, rb = blockIdx.y, b = blockIdx.z;
     if (cb < rb) return;  // words left of the diagonal are never read
     const int n = counts[b];
     if (rb * 64 >= n) return;  // rows past n are never read either
     __shared__ float4 col[64];
+    __shared__ float col_label[64];
     const int lane = threadIdx.x;
-    const float4 *bx = reinterpret_cast<const float4 *>(boxes) + (long)b * n_max;
+    const float *bx = boxes + (long)b * n_max * stride;
     const int cj = cb * 64 + lane;
-    col[lane] = cj < n ? bx[cj] : make_float4(0.f, 0.f, 0.f, 0.f);
+    col[lane] = cj < n ? load_box(bx, stride, cj) : make_float4(0.f, 0.f, 0.f, 0.f);
+    col_label[lane] = (label_col >= 0 && cj < n) ? bx[(long)cj * stride + label_col] : 0.f;
     __syncthreads();
     const int i = rb * 64 + lane;
     unsigned long long bits = 0;
     if (i < n) {
-        const float4 me = bx[i];
+        const float4 me = load_box(bx, stride, i);
+        const float my_label = label_col >= 0 ? bx[(long)i * stride + label_col] : 0.f;
         const int jmax = min(64, n - cb * 64);
         for (int j = 0; j < jmax; ++j) {
             const int gj = cb * 64 + j;
-            if (gj > i && iou_nms(me, col[j]) > thr) bits |= 1ull << j;
+            if (gj > i && col_label[j] == my_label && iou_nms(me, col[j]) > thr) bits |= 1ull << j;
         }
     }
     if (i < n_max) mask[((long)b * n_max + i) * words + cb] = bits;
@@ -59,9 +70,9 @@ nms_mask_kernel(const float *__restrict__ boxes, const int *__restrict__ counts,
 
 template <int WPL>  // mask words per lane = ceil(words / 64)
 __global__ void __launch_bounds__(64)
-nms_scan_kernel(const float *__restrict__ boxes, const int *__restrict__ counts, int n_max, int words, int n_post,
-                const unsigned long long *__restrict__ mask, int *__restrict__ keep_idx, float *__restrict__ rois,
-                int *__restrict__ n_kept_out, int *__restrict__ status) {
+nms_scan_kernel(const float *__restrict__ boxes, int stride, const int *__restrict__ counts, int n_max, int words,
+                int n_post, const unsigned long long *__restrict__ mask, int *__restrict__ keep_idx,
+                float *__restrict__ rois, int *__restrict__ n_kept_out, int *__restrict__ status, int pad) {
     extern __shared__ int s_keep[];  // n_post kept indices
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
@@ -117,21 +128,26 @@ nms_scan_kernel(const float *__restrict__ boxes, const int *__restrict__ counts,
     __syncthreads();
     const int n_kept = min(total, n_post);
     if (lane == 0) n_kept_out[b] = n_kept;
-    const float4 *bx = reinterpret_cast<const float4 *>(boxes) + (long)b * n_max;
+    const float *bx = boxes + (long)b * n_max * stride;
     for (int pos = lane; pos < n_post; pos += 64) {
         int src;
         bool bad = false;
         if (pos < n_kept) {
             src = s_keep[pos];
-        } else {
+        } else if (pad) {
             src = pos - n_kept;  // pad with 0,1,2,...  (nets/rpn.py:66-67)
             if (src >= n) { bad = true; src = 0; }
+        } else {
+            src = -1;            // no padding: rows past n_kept are marked empty
+            bad = true;
         }
         keep_idx[(long)b * n_post + pos] = src;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!bad) v = bx[src];
-        reinterpret_cast<float4 *>(rois)[(long)b * n_post + pos] = v;
-        if (bad) atomicOr(status, 1);
+        if (rois != nullptr) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!bad) v = load_box(bx, stride, src);
+            reinterpret_cast<float4 *>(rois)[(long)b * n_post + pos] = v;
+        }
+        if (bad && pad) atomicOr(status, 1);
     }
 }
 
@@ -160,24 +176,20 @@ extern "C" size_t tsod_nms_workspace_bytes(int32_t B, int32_t n_max) {
     return (size_t)B * (size_t)n_max * words * sizeof(unsigned long long);
 }
 
-extern "C" int tsod_nms_f32(const float *boxes, const int32_t *counts, int32_t B, int32_t n_max, float iou_thr,
-                            int32_t n_post, int32_t *keep_idx, float *rois, int32_t *n_kept, int32_t *status,
-                            void *workspace, size_t workspace_bytes, tsod_stream_t stream) {
-    TSOD_REQUIRE(boxes && counts && keep_idx && rois && n_kept && status, TSOD_ERR_INVALID_ARG);
-    TSOD_REQUIRE(B > 0 && n_max > 0 && n_post > 0, TSOD_ERR_INVALID_ARG);
-    TSOD_REQUIRE(n_max <= 16384 && n_post <= 8192, TSOD_ERR_UNSUPPORTED);
-    TSOD_REQUIRE(tsod_aligned16(boxes) && tsod_aligned16(rois), TSOD_ERR_ALIGNMENT);
-    TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= tsod_nms_workspace_bytes(B, n_max), TSOD_ERR_WORKSPACE);
+namespace {
+int launch_nms(const float *boxes, int stride, int label_col, const int32_t *counts, int B, int n_max, float iou_thr,
+               int n_post, int32_t *keep_idx, float *rois, int32_t *n_kept, int32_t *status, int pad, void *workspace,
+               tsod_stream_t stream) {
     const int words = (n_max + 63) / 64;
     unsigned long long *mask = static_cast<unsigned long long *>(workspace);
     hipStream_t s = tsod_stream(stream);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, s, boxes, counts, n_max, words, iou_thr,
-                       mask);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, s, boxes, stride, label_col, counts, n_max, words,
+                       iou_thr, mask);
     const size_t lds = (size_t)n_post * sizeof(int);
     const int wpl = (words + 63) / 64;
-#define TSOD_NMS_SCAN(W)                                                                                        \
-    hipLaunchKernelGGL(nms_scan_kernel<W>, dim3(B), dim3(64), lds, s, boxes, counts, n_max, words, n_post, mask, \
-                       keep_idx, rois, n_kept, status)
+#define TSOD_NMS_SCAN(W)                                                                                                \
+    hipLaunchKernelGGL(nms_scan_kernel<W>, dim3(B), dim3(64), lds, s, boxes, stride, counts, n_max, words, n_post, mask, \
+                       keep_idx, rois, n_kept, status, pad)
     switch (wpl) {
         case 1: TSOD_NMS_SCAN(1); break;
         case 2: TSOD_NMS_SCAN(2); break;
@@ -186,6 +198,29 @@ extern "C" int tsod_nms_f32(const float *boxes, const int32_t *counts, int32_t B
     }
 #undef TSOD_NMS_SCAN
     return tsod_launch_status();
+}
+}  // namespace
+
+extern "C" int tsod_nms_f32(const float *boxes, const int32_t *counts, int32_t B, int32_t n_max, float iou_thr,
+                            int32_t n_post, int32_t *keep_idx, float *rois, int32_t *n_kept, int32_t *status,
+                            void *workspace, size_t workspace_bytes, tsod_stream_t stream) {
+    TSOD_REQUIRE(boxes && counts && keep_idx && rois && n_kept && status, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(B > 0 && n_max > 0 && n_post > 0, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(n_max <= 16384 && n_post <= 8192, TSOD_ERR_UNSUPPORTED);
+    TSOD_REQUIRE(tsod_aligned16(boxes) && tsod_aligned16(rois), TSOD_ERR_ALIGNMENT);
+    TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= tsod_nms_workspace_bytes(B, n_max), TSOD_ERR_WORKSPACE);
+    return launch_nms(boxes, 4, -1, counts, B, n_max, iou_thr, n_post, keep_idx, rois, n_kept, status, 1, workspace, stream);
+}
+
+extern "C" int tsod_detection_nms_f32(const float *det_sorted, const int32_t *counts, int32_t B, int32_t R, float iou_thr,
+                                      int32_t per_class, int32_t *keep_idx, int32_t *n_kept, void *workspace,
+                                      size_t workspace_bytes, tsod_stream_t stream) {
+    TSOD_REQUIRE(det_sorted && counts && keep_idx && n_kept, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(B > 0 && R > 0, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(R <= 8192, TSOD_ERR_UNSUPPORTED);
+    TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= tsod_nms_workspace_bytes(B, R), TSOD_ERR_WORKSPACE);
+    return launch_nms(det_sorted, 6, per_class ? 5 : -1, counts, B, R, iou_thr, R, keep_idx, nullptr, n_kept, nullptr, 0,
+                      workspace, stream);
 }
 
 extern "C" int tsod_bbox_iou_f32(const float *a, int32_t Na, const float *b, int32_t Nb, float eps, float *out,

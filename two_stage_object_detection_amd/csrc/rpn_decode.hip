@@ -148,6 +148,33 @@ detections_kernel(const float *__restrict__ cls_locs, const float *__restrict__ 
     }
 }
 
+// Sort keys of the final decode: the record's score where it passes the threshold and is not the background class,
+// -inf (= dropped by tsod_sort_topk_desc_f32) otherwise.  NaN scores fail the comparison and are dropped.
+__global__ void __launch_bounds__(256)
+detection_keys_kernel(const float *__restrict__ det, long n, float score_thresh, int background_class,
+                      float *__restrict__ keys) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const float s = det[t * 6 + 4];
+        const float c = det[t * 6 + 5];
+        const bool ok = s >= score_thresh && (background_class < 0 || c != (float)background_class);
+        keys[t] = ok ? s : -INFINITY;
+    }
+}
+
+// out[b][r][:] = src[b][idx[b][r]][:], zero rows where idx < 0.
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const float *__restrict__ src, const int *__restrict__ idx, int B, int n, int m, int C,
+                   float *__restrict__ out) {
+    const long total = (long)B * m * C;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const long br = t / C;
+        const int b = (int)(br / m);
+        const int i = idx[br];
+        out[t] = (i >= 0 && i < n) ? src[((long)b * n + i) * C + c] : 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" int tsod_rpn_decode_f32(const float *locs, int32_t loc_pitch, const float *scores, int32_t score_pitch,
@@ -205,5 +232,24 @@ extern "C" int tsod_proposal_decode_f32(const float *anchor, const float *loc, c
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(proposal_decode_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), anchor, loc, score,
                        (long)n, clamp_x, clamp_y, min_size, boxes, keys);
+    return tsod_launch_status();
+}
+
+extern "C" int tsod_detection_keys_f32(const float *det, int64_t n, float score_thresh, int32_t background_class,
+                                       float *keys, tsod_stream_t stream) {
+    TSOD_REQUIRE(det && keys && n > 0, TSOD_ERR_INVALID_ARG);
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(detection_keys_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), det, (long)n, score_thresh,
+                       background_class, keys);
+    return tsod_launch_status();
+}
+
+extern "C" int tsod_gather_rows_f32(const float *src, const int32_t *idx, int32_t B, int32_t n, int32_t m, int32_t C,
+                                    float *out, tsod_stream_t stream) {
+    TSOD_REQUIRE(src && idx && out, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(B > 0 && n > 0 && m > 0 && C > 0, TSOD_ERR_INVALID_ARG);
+    const long total = (long)B * m * C;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), src, idx, B, n, m, C, out);
     return tsod_launch_status();
 }

@@ -282,3 +282,33 @@ def detections(cls_locs: torch.Tensor, scores: torch.Tensor, rois: torch.Tensor)
     check(lib().tsod_detections_f32(ptr(cls_locs.contiguous()), ptr(scores.contiguous()), ptr(rois.contiguous()), B * R,
                                     n_class, ptr(out), stream_ptr()), "detections")
     return out
+
+
+def filter_detections(det: torch.Tensor, iou_thr: float = 0.1, score_thresh: float | None = None, per_class: bool = False,
+                      background_class: int = -1):
+    """Inference-time filtering of detection records [B,R,6] (multi_inference.py:80-87 + the two deployment switches):
+    drop records below ``score_thresh`` / of ``background_class``, order by descending score (stable), greedy NMS
+    (class-agnostic like the reference's demo, or per class).  Returns (det_sorted [B,R,6], keep [B,R] i32 rows of
+    det_sorted in score order with -1 after n_kept[b], n_kept [B] i32)."""
+    require_cuda(det, "filter_detections")
+    det = det.contiguous()
+    B, R, six = det.shape
+    if six != 6:
+        raise ValueError("detection records are [B,R,6]")
+    dev = det.device
+    L = lib()
+    keys = torch.empty((B, R), dtype=torch.float32, device=dev)
+    thr = float("-inf") if score_thresh is None else float(score_thresh)
+    check(L.tsod_detection_keys_f32(ptr(det), B * R, thr, int(background_class), ptr(keys), stream_ptr()), "detection_keys")
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    idx = torch.empty((B, R), dtype=torch.int32, device=dev)
+    check(L.tsod_sort_topk_desc_f32(ptr(keys), None, B, R, R, ptr(counts), ptr(idx), None, None, stream_ptr()), "sort_topk")
+    det_sorted = torch.empty_like(det)
+    check(L.tsod_gather_rows_f32(ptr(det), ptr(idx), B, R, R, 6, ptr(det_sorted), stream_ptr()), "gather_rows")
+    keep = torch.empty((B, R), dtype=torch.int32, device=dev)
+    n_kept = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws_bytes = L.tsod_nms_workspace_bytes(B, R)
+    ws = ARENA.get(dev, ws_bytes)
+    check(L.tsod_detection_nms_f32(ptr(det_sorted), ptr(counts), B, R, float(iou_thr), 1 if per_class else 0, ptr(keep),
+                                   ptr(n_kept), ptr(ws), ws_bytes, stream_ptr()), "detection_nms")
+    return det_sorted, keep, n_kept

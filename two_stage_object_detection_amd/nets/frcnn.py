@@ -92,20 +92,26 @@ class FasterRCNN(nn.Module):
         remapped = {("extractor." + k[len("feat_extra."):] if k.startswith("feat_extra.") else k): v for k, v in sd.items()}
         return self.load_state_dict(remapped, strict=strict)
 
-    def postprocess(self, det, iou_threshold=0.1):
+    def postprocess(self, det, iou_threshold=0.1, score_thresh=None, per_class=False, background_class=-1):
         """The inference-time filtering of the reference's demo script (multi_inference.py:80-87): per image,
         class-agnostic ``nms(boxes_pred, labels_score_pred, iou_threshold)`` over the decoded per-RoI boxes with the
         arg-max logit as score.  det [B,R,6] from ``detections()`` -> (det_sorted [B,R,6] in descending-score order,
-        keep [B,R] int32 indices into det_sorted, n_kept [B] int32): the survivors of image b are
-        ``det_sorted[b][keep[b, :n_kept[b]].long()]``.  Same HIP kernels as the proposal path (top-k sort + bitmask NMS)."""
+        keep [B,R] int32 indices into det_sorted (-1 after n_kept), n_kept [B] int32): the survivors of image b are
+        ``det_sorted[b][keep[b, :n_kept[b]].long()]``.  The defaults are the reference's behaviour; ``score_thresh``,
+        ``background_class`` and ``per_class`` are the switches of a deployed detector.  Four
+        libtsod launches (keys, top-k sort, row gather, bitmask NMS), no torch kernels."""
         require_cuda(det, "FasterRCNN.postprocess")
-        B, R, _ = det.shape
-        boxes = det[..., :4].contiguous()
-        scores = det[..., 4].contiguous()
-        counts, idx, boxes_sorted, _ = hip_ops.sort_topk_desc(scores, boxes, R)
-        keep, _, n_kept, _ = hip_ops.nms_sorted(boxes_sorted, counts, iou_threshold, R)
-        det_sorted = torch.gather(det, 1, idx.long().clamp_min(0).unsqueeze(-1).expand(B, R, 6))   # layout plumbing only
-        return det_sorted, keep, n_kept
+        return hip_ops.filter_detections(det, iou_threshold, score_thresh, per_class, background_class)
+
+    def predict(self, x, scale=1., iou_threshold=0.1, score_thresh=None, per_class=False, background_class=-1):
+        """forward -> detection records -> ``postprocess``: list (one entry per image) of [n_i,6] tensors
+        (x1,y1,x2,y2,score,class) in descending-score order.  The only host synchronisation is reading n_kept."""
+        outs = self.forward(x, scale)
+        det = hip_ops.detections(outs[0], outs[1], outs[2])
+        det_sorted, keep, n_kept = self.postprocess(det, iou_threshold, score_thresh, per_class, background_class)
+        self.raise_if_error()
+        ns = n_kept.tolist()
+        return [det_sorted[b][keep[b, :ns[b]].long()] for b in range(det.shape[0])]
 
     def make_graphed(self, x_example, slot=0):
         """Capture forward + detection records for this input geometry into ONE HIP graph.
