@@ -248,6 +248,28 @@ int tsod_detection_nms_f32(const float *det_sorted, const int32_t *counts, int32
                            int32_t per_class, int32_t *keep_idx, int32_t *n_kept, void *workspace,
                            size_t workspace_bytes, tsod_stream_t stream);
 
+/* ---- input step (the step before the path) ----------------------------------------------
+ * dataset/dataloader.py:35-44 + dataset/transform.py:14-17: a decoded RGB image becomes an f32 CHW tensor with
+ * values 0..255 and is resized to the detector's fixed size by torchvision v2 Resize, i.e. ATen's antialiased
+ * bilinear interpolation (align_corners = false).  Here: u8 HWC in device memory -> f32, resized, already in the
+ * layout the backbone reads (NHWC with a zero 4th channel, or NCHW).
+ *   tsod_resize_aa_taps(in, out)      taps per output index of one axis (row length of the weight table)
+ *   tsod_resize_aa_tables_f32         HOST function: first[out], count[out], weights[out][taps] of one axis in
+ *                                     ATen's f32 arithmetic (triangle filter widened by the down-scale factor,
+ *                                     normalised per output index); copy the tables to the device once per size pair
+ *   tsod_resize_bilinear_aa_u8_f32    out[oy*stride_y + ox*stride_x + c*stride_c] =
+ *                                       mul * sum_j wy[oy][j] * (sum_i wx[ox][i] * src[y0+j][x0+i][c]),  c < C;
+ *                                     channels C..C_out-1 are written as 0.  Strides in floats:
+ *                                     NHWC4 = (4*OW, 4, 1) with C_out = 4;  NCHW plane = (OW, 1, OH*OW) with C_out = C.
+ *                                     mul = 1 reproduces the reference (values stay 0..255), 1/255 gives [0,1]. */
+int32_t tsod_resize_aa_taps(int32_t in_size, int32_t out_size);
+int tsod_resize_aa_tables_f32(int32_t in_size, int32_t out_size, int32_t *first, int32_t *count, float *weights);
+int tsod_resize_bilinear_aa_u8_f32(const uint8_t *src, int32_t H, int32_t W, int32_t C, int64_t src_row_bytes,
+                                   const int32_t *yfirst, const int32_t *ycount, const float *ywt,
+                                   const int32_t *xfirst, const int32_t *xcount, const float *xwt, int32_t OH,
+                                   int32_t OW, float mul, float *out, int64_t stride_y, int64_t stride_x,
+                                   int64_t stride_c, int32_t C_out, tsod_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

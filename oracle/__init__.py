@@ -13,6 +13,8 @@ Pinning status (see DESIGN.md "Oracle"):
 * ``nms`` and ``roi_pool`` (torchvision, absent from /root/reference and from the image,
   version unpinned by the reference): PARITY UNPINNED -- restated from the published
   algorithm, pinned only by hand-derived known-answer cases.
+* ``eval_transform`` (torchvision v2 Resize + ToTensor on a float tensor image): PARITY UNPINNED for
+  the torchvision glue; the arithmetic is torch's own antialiased bilinear ``interpolate`` (oracle/transform.py).
 """
 from .box import (  # noqa: F401
     generate_basic_anchor, enumerate_shifted_anchor, loc2bbox, bbox_iou,
@@ -20,3 +22,4 @@ from .box import (  # noqa: F401
 )
 from .backbones import resnet_trunk, hardnet_trunk, calibrate_bn  # noqa: F401
 from .detector import detector_forward, detections_from_outputs, postprocess  # noqa: F401
+from .transform import eval_transform  # noqa: F401

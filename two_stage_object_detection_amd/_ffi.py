@@ -75,6 +75,11 @@ _SIGNATURES = {
     "tsod_roi_pool_avg_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
                                       c_float, c_float, c_float, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "tsod_detections_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "tsod_resize_aa_taps": (c_int32, [c_int32, c_int32]),
+    "tsod_resize_aa_tables_f32": (c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "tsod_resize_bilinear_aa_u8_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p, c_int64,
+                                               c_int64, c_int64, c_int32, c_void_p]),
     "tsod_detection_keys_f32": (c_int, [c_void_p, c_int64, c_float, c_int32, c_void_p, c_void_p]),
     "tsod_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "tsod_detection_nms_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p, c_void_p, c_void_p,
@@ -115,7 +120,33 @@ def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
 
-def require_cuda(t: torch.Tensor, what: str) -> None:
+class NHWC4Images:
+    """A batch of images already in the backbone's input layout: ``data`` is [N,H,W,4] f32 on the GPU (RGB + a zero
+    4th channel), as written by ``dataset.transform.EvalTransform.batch``.  ``shape`` reports the NCHW shape the
+    reference's code reads (``x.shape[1:]`` = (3,H,W), nets/frcnn.py:33), so the detector accepts it wherever it accepts
+    an NCHW tensor and skips its own layout kernel."""
+
+    def __init__(self, data: torch.Tensor):
+        if data.dim() != 4 or data.shape[3] != 4 or data.dtype != torch.float32 or not data.is_contiguous():
+            raise TsodError(f"NHWC4Images needs a contiguous f32 [N,H,W,4] tensor, got {tuple(data.shape)} {data.dtype}")
+        self.data = data
+
+    @property
+    def shape(self):
+        n, h, w, _ = self.data.shape
+        return torch.Size((n, 3, h, w))
+
+    device = property(lambda self: self.data.device)
+    is_cuda = property(lambda self: self.data.is_cuda)
+    dtype = property(lambda self: self.data.dtype)
+
+    def dim(self):
+        return 4
+
+
+def require_cuda(t, what: str) -> None:
+    if isinstance(t, NHWC4Images):
+        t = t.data
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise TsodError(f"{what}: this package is a HIP-only path and needs a CUDA/ROCm tensor "
                         "(the CPU restatement lives under oracle/ and is test infrastructure only)")

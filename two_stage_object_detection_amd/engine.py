@@ -286,3 +286,17 @@ class Plan:
             lib().tsod_conv2d_resolve(byref(st.desc), byref(t), byref(s))
             out.append((st.name, t.value, s.value))
         return out
+
+
+def stage_input(plan: "Plan", x) -> None:
+    """Put the images of one forward into the plan's NHWC(4) input buffer: NCHW tensors go through the layout kernel
+    (tsod_nchw_to_nhwc_f32), ``NHWC4Images`` are already in layout (no launch at all when they were written straight
+    into ``plan.input_nhwc``, see ``input_buffer`` of the backbones)."""
+    from ._ffi import NHWC4Images
+    if isinstance(x, NHWC4Images):
+        if x.data.data_ptr() != plan.input_nhwc.data_ptr():
+            plan.input_nhwc.copy_(x.data)
+        return
+    x = x.contiguous()
+    N, _, H, W = x.shape
+    check(lib().tsod_nchw_to_nhwc_f32(ptr(x), N, 3, H, W, ptr(plan.input_nhwc), 4, 4, stream_ptr()), "nchw_to_nhwc")

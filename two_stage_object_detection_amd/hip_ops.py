@@ -312,3 +312,51 @@ def filter_detections(det: torch.Tensor, iou_thr: float = 0.1, score_thresh: flo
     check(L.tsod_detection_nms_f32(ptr(det_sorted), ptr(counts), B, R, float(iou_thr), 1 if per_class else 0, ptr(keep),
                                    ptr(n_kept), ptr(ws), ws_bytes, stream_ptr()), "detection_nms")
     return det_sorted, keep, n_kept
+
+
+# ----------------------------------------------------------------------------- input step
+_RESIZE_TABLES: dict = {}
+
+
+def resize_tables(n_in: int, n_out: int, device):
+    """(first [n_out] i32, count [n_out] i32, weights [n_out,taps] f32) of one axis on ``device``; computed by the
+    library's host function once per (n_in, n_out, device)."""
+    import numpy as np
+    key = (int(n_in), int(n_out), torch.device(device))
+    t = _RESIZE_TABLES.get(key)
+    if t is None:
+        L = lib()
+        taps = L.tsod_resize_aa_taps(n_in, n_out)
+        first = np.zeros(n_out, np.int32)
+        count = np.zeros(n_out, np.int32)
+        w = np.zeros((n_out, taps), np.float32)
+        check(L.tsod_resize_aa_tables_f32(n_in, n_out, first.ctypes.data, count.ctypes.data, w.ctypes.data), "resize_tables")
+        t = _RESIZE_TABLES[key] = tuple(torch.from_numpy(a).to(device) for a in (first, count, w))
+    return t
+
+
+def resize_bilinear_aa(img: torch.Tensor, OH: int, OW: int, layout: str = "nhwc4", mul: float = 1.0, out=None):
+    """u8 [H,W,C<=4] CUDA image -> antialiased-bilinear resized f32 image: ``layout="nhwc4"`` -> [OH,OW,4] (extra channels
+    zero), ``"nchw"`` -> [C,OH,OW]  (dataset/transform.py:14-17 on the GPU)."""
+    if not isinstance(img, torch.Tensor) or not img.is_cuda or img.dtype != torch.uint8 or img.dim() != 3:
+        raise TsodError("resize_bilinear_aa: a u8 [H,W,C] CUDA/ROCm tensor is required")
+    H, W, C = img.shape
+    if not 1 <= C <= 4 or img.stride(2) != 1 or img.stride(1) != C:
+        raise TsodError("resize_bilinear_aa: pixels must be interleaved and contiguous along a row")
+    dev = img.device
+    yf, yc, yw = resize_tables(H, OH, dev)
+    xf, xc, xw = resize_tables(W, OW, dev)
+    if layout == "nhwc4":
+        shape, strides, c_out = (OH, OW, 4), (4 * OW, 4, 1), 4
+    elif layout == "nchw":
+        shape, strides, c_out = (C, OH, OW), (OW, 1, OH * OW), C
+    else:
+        raise ValueError(layout)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+    if tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+        raise TsodError(f"resize_bilinear_aa: out must be a contiguous f32 {shape} tensor on {dev}")
+    check(lib().tsod_resize_bilinear_aa_u8_f32(ptr(img), H, W, C, img.stride(0), ptr(yf), ptr(yc), ptr(yw), ptr(xf), ptr(xc),
+                                               ptr(xw), OH, OW, float(mul), ptr(out), strides[0], strides[1], strides[2],
+                                               c_out, stream_ptr()), "resize_bilinear_aa")
+    return out

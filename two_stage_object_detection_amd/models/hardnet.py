@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from .. import hip_ops
 from .._ffi import ACT_NONE, ACT_RELU6, TsodError, lib, ptr, require_cuda
-from ..engine import PackedConv, Plan, fold_bn
+from ..engine import stage_input, PackedConv, Plan, fold_bn
 
 
 def _pad4(c: int) -> int:
@@ -340,13 +340,28 @@ class HarDNetFeatureExtraction(nn.Module):
         return plan
 
     def forward_nhwc(self, x, slot: int = 0):
+        """[N,3,H,W] (or NHWC4Images) -> NHWC feature map (plan-owned buffer, valid until the next forward)."""
         plan = self._plan_for(x, slot)
-        x = x.contiguous()
-        N, _, H, W = x.shape
-        hip_ops.check(lib().tsod_nchw_to_nhwc_f32(ptr(x), N, 3, H, W, ptr(plan.input_nhwc), 4, 4, hip_ops.stream_ptr()),
-                      "nchw_to_nhwc")
+        stage_input(plan, x)
         plan.run()
         return plan.output_nhwc
+
+    def input_buffer(self, N, H, W, device, slot: int = 0):
+        """The plan's own input buffer for [N,3,H,W] images as ``NHWC4Images``: an input pipeline that writes there
+        (dataset.transform.EvalTransform.batch(..., out=...)) hands its result to the first conv without any copy."""
+        from .._ffi import NHWC4Images
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise TsodError("input_buffer: a CUDA/ROCm device is required")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        key = ((N, 3, H, W), device, slot)
+        plan = self._plans.get(key)
+        if plan is None:
+            if self.training:
+                raise TsodError("the HIP path implements the inference forward only: call .eval() first")
+            plan = self._plans[key] = self.build_plan(N, H, W, device)
+        return NHWC4Images(plan.input_nhwc)
 
     def forward(self, x):
         return hip_ops.nhwc_to_nchw(self.forward_nhwc(x))

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import hip_ops
 from .._ffi import ACT_NONE, ACT_PRELU, TsodError, lib, ptr, require_cuda
-from ..engine import PackedConv, Plan, prelu_slope
+from ..engine import stage_input, PackedConv, Plan, prelu_slope
 
 
 def _conv(cin, cout, k, stride=1, pad=0, groups=1):
@@ -171,14 +171,28 @@ class ResNet(nn.Module):
         return plan
 
     def forward_nhwc(self, x: torch.Tensor, slot: int = 0) -> torch.Tensor:
-        """[N,3,H,W] -> NHWC feature [N,H/32,W/32,C] (plan-owned buffer, valid until the next forward)."""
+        """[N,3,H,W] (or NHWC4Images) -> NHWC feature map (plan-owned buffer, valid until the next forward)."""
         plan = self._plan_for(x, slot)
-        x = x.contiguous()
-        N, _, H, W = x.shape
-        hip_ops.check(lib().tsod_nchw_to_nhwc_f32(ptr(x), N, 3, H, W, ptr(plan.input_nhwc), 4, 4, hip_ops.stream_ptr()),
-                      "nchw_to_nhwc")
+        stage_input(plan, x)
         plan.run()
         return plan.output_nhwc
+
+    def input_buffer(self, N, H, W, device, slot: int = 0):
+        """The plan's own input buffer for [N,3,H,W] images as ``NHWC4Images``: an input pipeline that writes there
+        (dataset.transform.EvalTransform.batch(..., out=...)) hands its result to the first conv without any copy."""
+        from .._ffi import NHWC4Images
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise TsodError("input_buffer: a CUDA/ROCm device is required")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        key = ((N, 3, H, W), device, slot)
+        plan = self._plans.get(key)
+        if plan is None:
+            if self.training:
+                raise TsodError("the HIP path implements the inference forward only: call .eval() first")
+            plan = self._plans[key] = self.build_plan(N, H, W, device)
+        return NHWC4Images(plan.input_nhwc)
 
     def forward(self, x):
         feat = self.forward_nhwc(x)
