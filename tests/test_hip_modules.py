@@ -348,3 +348,36 @@ def test_hip_graph_replay_is_bit_identical(dev, synth):
         plan.graph = None
     for a, b in zip(eager, replay):
         assert torch.equal(a, b)
+
+
+def test_in_flight_detector_returns_each_requests_own_result(dev, synth):
+    """serving.InFlightDetector: requests issued round-robin on several streams / graphs / buffer sets; every ticket
+    returns exactly what a plain forward of its images returns (same kernels, same tile choices)."""
+    from two_stage_object_detection_amd import hip_ops
+    from two_stage_object_detection_amd.serving import InFlightDetector
+    model, _ = synth("resnet50")
+    xs = [_img((1, 3, 224, 288), seed=40 + i).to(dev) for i in range(7)]
+    server = InFlightDetector(model, xs[0], depth=3)
+    with torch.inference_mode():
+        refs = []
+        for x in xs:
+            o = model(x)
+            refs.append([t.clone() for t in o] + [hip_ops.detections(o[0], o[1], o[2])])
+    tickets = [server.submit(x) for x in xs[:3]]
+    got = {t: [o.clone() for o in server.result(t)] for t in tickets}
+    for x in xs[3:]:                                              # keep the pipe full: submit one, collect the oldest
+        t = server.submit(x)
+        got[t] = None
+        oldest = t - 2
+        if got.get(oldest) is None:
+            got[oldest] = [o.clone() for o in server.result(oldest)]
+    for t in list(got):
+        if got[t] is None:
+            got[t] = [o.clone() for o in server.result(t)]
+    server.drain()
+    assert sorted(got) == list(range(7))
+    for t, outs in got.items():
+        for a, b in zip(outs, refs[t]):
+            assert torch.equal(a, b), f"ticket {t}"
+    with pytest.raises(Exception):
+        server.result(0)                                          # slot 0 has been reused since

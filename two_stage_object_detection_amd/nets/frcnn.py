@@ -136,7 +136,8 @@ class FasterRCNN(nn.Module):
 
         def run(x=None):
             if x is not None:
-                static_in.copy_(x, non_blocking=True)
+                with torch.inference_mode():                    # static_in may have been created under inference mode
+                    static_in.copy_(x, non_blocking=True)
             graph.replay()
             return static_out
         return run, static_in, static_out
