@@ -192,7 +192,7 @@ class Plan:
             self.launch()                      # warm-up outside capture
         side.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
             self.launch()
         self.graph = g
         return self

@@ -129,7 +129,8 @@ class FasterRCNN(nn.Module):
                 hip_ops.detections(outs[0], outs[1], outs[2])
         side.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.inference_mode(), torch.cuda.graph(graph, stream=side):
+        # thread_local: another thread of the process (e.g. RCCL's watchdog polling its events) must not abort the capture
+        with torch.inference_mode(), torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
             outs = self.forward(static_in, slot=slot)
             det = hip_ops.detections(outs[0], outs[1], outs[2])
         static_out = tuple(outs) + (det,)
