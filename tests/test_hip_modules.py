@@ -381,3 +381,41 @@ def test_in_flight_detector_returns_each_requests_own_result(dev, synth):
             assert torch.equal(a, b), f"ticket {t}"
     with pytest.raises(Exception):
         server.result(0)                                          # slot 0 has been reused since
+
+
+@pytest.mark.parametrize("backbone", ["resnet50", "hardnet39"])
+def test_images_too_small_for_300_proposals_raise_like_the_reference(dev, synth, backbone):
+    """A 32x32 / 64x96 image has fewer anchors than n_post: the reference's pad (nets/rpn.py:65-69) raises IndexError,
+    and so do the oracle and - deferred to raise_if_error(), inside or outside inference mode - the HIP path."""
+    model, sd = synth(backbone)
+    for shape in ((1, 3, 32, 32), (2, 3, 64, 96)):
+        x = _img(shape, seed=50)
+        with pytest.raises(IndexError):
+            oracle.detector_forward(sd, x, backbone=backbone)
+        with torch.inference_mode():
+            model(x.to(dev))
+        with pytest.raises(IndexError):
+            model.raise_if_error()
+        model.raise_if_error()                                   # the error word is cleared once reported
+        with torch.inference_mode():
+            model(x.to(dev))
+            with pytest.raises(IndexError):
+                model.raise_if_error()
+
+
+def test_forward_needs_no_grad_mode_context(dev, synth):
+    """Callers of the reference wrap inference in torch.no_grad() or nothing at all: the HIP path never touches autograd,
+    so plain calls, no_grad and inference_mode give the same tensors (and none of them requires grad)."""
+    from two_stage_object_detection_amd._ffi import NHWC4Images
+    model, _ = synth("resnet50")
+    x = _img((1, 3, 224, 256), seed=60).to(dev)
+    with torch.inference_mode():
+        ref = [o.clone() for o in model(x)]
+    plain = model(x)
+    with torch.no_grad():
+        ng = model(x)
+    staged = model(NHWC4Images(x.permute(0, 2, 3, 1).contiguous().new_zeros((1, 224, 256, 4)).copy_(
+        torch.cat([x.permute(0, 2, 3, 1), torch.zeros(1, 224, 256, 1, device=dev)], dim=-1))))
+    for a, b, c, d in zip(ref, plain, ng, staged):
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d) and not b.requires_grad
+    model.raise_if_error()

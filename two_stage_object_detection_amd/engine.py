@@ -295,7 +295,8 @@ def stage_input(plan: "Plan", x) -> None:
     from ._ffi import NHWC4Images
     if isinstance(x, NHWC4Images):
         if x.data.data_ptr() != plan.input_nhwc.data_ptr():
-            plan.input_nhwc.copy_(x.data)
+            with torch.inference_mode():                # the plan's buffers may have been allocated under inference mode
+                plan.input_nhwc.copy_(x.data)
         return
     x = x.contiguous()
     N, _, H, W = x.shape

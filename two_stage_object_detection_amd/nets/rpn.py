@@ -67,7 +67,8 @@ class ProposalCreator:
     def raise_if_error(self):
         st = getattr(self, "last_status", None)
         if st is not None and int(st.item()) & 1:
-            st.zero_()
+            with torch.inference_mode():            # the word may have been allocated under inference mode
+                st.zero_()
             raise IndexError("proposal padding needs more candidates than survive the min-size filter "
                              "(the reference raises IndexError at nets/rpn.py:69)")
 
