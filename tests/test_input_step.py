@@ -12,7 +12,8 @@ from two_stage_object_detection_amd._ffi import lib
 
 TOL = 1e-3
 SIZES = [((97, 131), (60, 60)), ((50, 40), (60, 60)), ((480, 640), (600, 600)), ((233, 517), (100, 77)),
-         ((1, 1), (5, 7)), ((7, 5), (1, 1)), ((1080, 1920), (600, 600)), ((600, 600), (600, 600))]
+         ((1, 1), (5, 7)), ((7, 5), (1, 1)), ((1080, 1920), (600, 600)), ((600, 600), (600, 600)),
+         ((540, 960), (30, 30)), ((31, 1000), (31, 40)), ((33, 47), (257, 129))]   # 18x down-scale: the untiled kernel
 
 
 def _image(shape, seed=0, C=3):

@@ -56,6 +56,90 @@ resize_aa_kernel(const unsigned char *__restrict__ src, int H, int W, int C, lon
     }
 }
 
+// Tiled form: a 256-thread workgroup owns TY x TX output pixels, stages the u8 input region those pixels touch into
+// LDS with coalesced aligned dword loads (every input byte is fetched from global memory once per tile instead of once
+// per tap), then every thread runs the same horizontal-then-vertical f32 sums as above out of LDS.  The region of a
+// tile is [first[o0], first[oL] + count[oL]) per axis (both are non-decreasing in the output index).
+constexpr int kTY = 8, kTX = 32;
+
+__global__ void __launch_bounds__(kTY * kTX)
+resize_aa_tile_kernel(const unsigned char *__restrict__ src, int H, int W, int C, long src_row_bytes,
+                      const int *__restrict__ yfirst, const int *__restrict__ ycount, const float *__restrict__ ywt,
+                      int ytaps, const int *__restrict__ xfirst, const int *__restrict__ xcount,
+                      const float *__restrict__ xwt, int xtaps, int OH, int OW, float mul, float *__restrict__ out,
+                      long stride_y, long stride_x, long stride_c, int C_out, int cap_rows, int cap_row_bytes) {
+    extern __shared__ __align__(16) unsigned char region[];          // cap_rows x cap_row_bytes, then the tile's weights
+    const int tiles_x = (OW + kTX - 1) / kTX;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int oy0 = ty * kTY, ox0 = tx * kTX;
+    const int oyL = min(oy0 + kTY, OH) - 1, oxL = min(ox0 + kTX, OW) - 1;
+    const int ry0 = yfirst[oy0], rx0 = xfirst[ox0];
+    const int rows = min(yfirst[oyL] + ycount[oyL] - ry0, cap_rows);
+    const int row_bytes = (xfirst[oxL] + xcount[oxL] - rx0) * C;
+    // row r of the region starts at global byte address g_r = src + (ry0 + r) * pitch + rx0 * C; LDS holds the aligned
+    // dwords from g_r - (g_r & 3) on, so a consumer adds that misalignment back
+    const unsigned long long base = reinterpret_cast<unsigned long long>(src) + (unsigned long long)rx0 * C;
+    const int words_cap = cap_row_bytes >> 2;
+    for (int r = threadIdx.x / 32; r < rows; r += (kTY * kTX) / 32) {
+        const unsigned long long g = base + (unsigned long long)(ry0 + r) * src_row_bytes;
+        const int mis = (int)(g & 3ull);
+        const int words = min((row_bytes + mis + 3) >> 2, words_cap);
+        const unsigned *gw = reinterpret_cast<const unsigned *>(g - mis);
+        unsigned *lw = reinterpret_cast<unsigned *>(region + (long)r * cap_row_bytes);
+        for (int w = threadIdx.x % 32; w < words; w += 32) lw[w] = gw[w];
+    }
+    // the tile's weight rows go to LDS as well: the tap loops below then touch no global memory at all
+    float *s_wx = reinterpret_cast<float *>(region + (long)cap_rows * cap_row_bytes);
+    float *s_wy = s_wx + kTX * xtaps;
+    for (int t = threadIdx.x; t < kTX * xtaps; t += kTY * kTX) {
+        const int o = ox0 + t / xtaps;
+        s_wx[t] = o < OW ? xwt[(long)o * xtaps + t % xtaps] : 0.f;
+    }
+    for (int t = threadIdx.x; t < kTY * ytaps; t += kTY * kTX) {
+        const int o = oy0 + t / ytaps;
+        s_wy[t] = o < OH ? ywt[(long)o * ytaps + t % ytaps] : 0.f;
+    }
+    __syncthreads();
+    const int ox = ox0 + (threadIdx.x % kTX), oy = oy0 + (threadIdx.x / kTX);
+    if (ox >= OW || oy >= OH) return;
+    const int x0 = xfirst[ox], nx = xcount[ox];
+    const int y0 = yfirst[oy], ny = ycount[oy];
+    const float *wx = s_wx + (threadIdx.x % kTX) * xtaps;
+    const float *wy = s_wy + (threadIdx.x / kTX) * ytaps;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < ny; ++j) {
+        const int r = y0 + j - ry0;
+        const int mis = (int)((base + (unsigned long long)(y0 + j) * src_row_bytes) & 3ull);
+        const unsigned char *row = region + (long)min(r, cap_rows - 1) * cap_row_bytes + mis + (x0 - rx0) * C;
+        float h[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < nx; ++i) {
+            const float w = wx[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < C) {
+                    const float v = (float)row[i * C + c] * w;
+                    h[c] = i == 0 ? v : h[c] + v;
+                }
+        }
+        const float w = wy[j];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float v = h[c] * w;
+            acc[c] = j == 0 ? v : acc[c] + v;
+        }
+    }
+    float *o = out + oy * stride_y + ox * stride_x;
+    if (stride_c == 1 && C_out == 4 && ((stride_x | stride_y) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
+        // NHWC(4): one 16-byte store per pixel
+        *reinterpret_cast<float4 *>(o) = make_float4(acc[0] * mul, C > 1 ? acc[1] * mul : 0.f, C > 2 ? acc[2] * mul : 0.f,
+                                                     C > 3 ? acc[3] * mul : 0.f);
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < C_out) o[c * stride_c] = c < C ? acc[c] * mul : 0.f;
+}
+
 }  // namespace
 
 extern "C" int32_t tsod_resize_aa_taps(int32_t in_size, int32_t out_size) {
@@ -108,10 +192,24 @@ extern "C" int tsod_resize_bilinear_aa_u8_f32(const uint8_t *src, int32_t H, int
     TSOD_REQUIRE(src && yfirst && ycount && ywt && xfirst && xcount && xwt && out, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(H > 0 && W > 0 && OH > 0 && OW > 0 && C >= 1 && C <= 4 && C_out >= C && C_out <= 4, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(src_row_bytes >= (int64_t)W * C, TSOD_ERR_INVALID_ARG);
-    const long total = (long)OH * OW;
+    const int ytaps = tsod_resize_aa_taps(H, OH), xtaps = tsod_resize_aa_taps(W, OW);
+    // LDS the tiled form needs for the largest region a tile can touch: (T-1)*scale + taps + 2 input rows / columns
+    const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+    const int cap_rows = (int)ceilf((kTY - 1) * sy) + ytaps + 2;
+    const int cap_cols = (int)ceilf((kTX - 1) * sx) + xtaps + 2;
+    const int cap_row_bytes = ((cap_cols * C + 3 + 3) / 4) * 4;
+    const size_t lds = (size_t)cap_rows * cap_row_bytes + (size_t)(kTX * xtaps + kTY * ytaps) * sizeof(float);
+    if (lds <= 48 * 1024) {
+        const int tiles = ((OH + kTY - 1) / kTY) * ((OW + kTX - 1) / kTX);
+        hipLaunchKernelGGL(resize_aa_tile_kernel, dim3(tiles), dim3(kTY * kTX), lds, tsod_stream(stream), src, H, W, C,
+                           (long)src_row_bytes, yfirst, ycount, ywt, ytaps, xfirst, xcount, xwt, xtaps, OH, OW, mul, out,
+                           (long)stride_y, (long)stride_x, (long)stride_c, C_out, cap_rows, cap_row_bytes);
+        return tsod_launch_status();
+    }
+    const long total = (long)OH * OW;                       // very large down-scales: every tap straight from global memory
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(resize_aa_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), src, H, W, C, (long)src_row_bytes,
-                       yfirst, ycount, ywt, tsod_resize_aa_taps(H, OH), xfirst, xcount, xwt, tsod_resize_aa_taps(W, OW), OH,
-                       OW, mul, out, (long)stride_y, (long)stride_x, (long)stride_c, C_out);
+                       yfirst, ycount, ywt, ytaps, xfirst, xcount, xwt, xtaps, OH, OW, mul, out, (long)stride_y,
+                       (long)stride_x, (long)stride_c, C_out);
     return tsod_launch_status();
 }
