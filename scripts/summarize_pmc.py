@@ -53,9 +53,9 @@ print("## HBM traffic of the memory-bound kernels (passes 2 and 3: FETCH_SIZE, W
 print("| kernel | avg us | FETCH_SIZE KB | WRITE_SIZE KB | HBM MB = (2*FETCH+WRITE)*1024/1e6 | achieved GB/s (PMC bytes / time) | algorithmic MB (DESIGN.md section 4) |")
 print("|---|---:|---:|---:|---:|---:|---:|")
 alg = {'maxpool3x3s2_kernel': 85.4, 'nchw_to_nhwc_small_kernel': 29.9, 'rpn_decode_kernel': 0.42, 'roi_pool_avg_kernel': 11.1,
-       'nms_mask_kernel': 1.18, 'nms_scan_kernel<1>': 1.13, 'sort_topk_kernel<10>': 0.11, 'detections_kernel': 0.5}
+       'nms_mask_kernel<4, -1>': 1.18, 'nms_scan_kernel<1>': 1.13, 'sort_topk_kernel<10>': 0.11, 'detections_kernel': 0.5}
 for k in ['nchw_to_nhwc_small_kernel', 'maxpool3x3s2_kernel', 'conv_reduce_kernel', 'rpn_decode_kernel', 'sort_topk_kernel<10>',
-          'nms_mask_kernel', 'nms_scan_kernel<1>', 'roi_pool_avg_kernel', 'detections_kernel']:
+          'nms_mask_kernel<4, -1>', 'nms_scan_kernel<1>', 'roi_pool_avg_kernel', 'detections_kernel']:
     if k not in fe:
         continue
     ds = list(fe[k].items()); ds = ds[len(ds) // 2:]

@@ -38,10 +38,12 @@ __device__ __forceinline__ float4 load_box(const float *__restrict__ base, int s
     return make_float4(q[0], q[1], q[2], q[3]);
 }
 
-// label_col >= 0: column of the row that holds the class; pairs of different classes never suppress each other.
+// LABEL_COL >= 0: column of the row that holds the class; pairs of different classes never suppress each other.
+template <int STRIDE, int LABEL_COL>
 __global__ void __launch_bounds__(64)
-nms_mask_kernel(const float *__restrict__ boxes, int stride, int label_col, const int *__restrict__ counts, int n_max,
-                int words, float thr, unsigned long long *__restrict__ mask) {
+nms_mask_kernel(const float *__restrict__ boxes, const int *__restrict__ counts, int n_max, int words, float thr,
+                unsigned long long *__restrict__ mask) {
+    constexpr int stride = STRIDE, label_col = LABEL_COL;
     const int cb = blockIdx.x, rb = blockIdx.y, b = blockIdx.z;
     if (cb < rb) return;  // words left of the diagonal are never read
     const int n = counts[b];
@@ -62,7 +64,7 @@ nms_mask_kernel(const float *__restrict__ boxes, int stride, int label_col, cons
         const int jmax = min(64, n - cb * 64);
         for (int j = 0; j < jmax; ++j) {
             const int gj = cb * 64 + j;
-            if (gj > i && col_label[j] == my_label && iou_nms(me, col[j]) > thr) bits |= 1ull << j;
+            if (gj > i && (label_col < 0 || col_label[j] == my_label) && iou_nms(me, col[j]) > thr) bits |= 1ull << j;
         }
     }
     if (i < n_max) mask[((long)b * n_max + i) * words + cb] = bits;
@@ -183,8 +185,15 @@ int launch_nms(const float *boxes, int stride, int label_col, const int32_t *cou
     const int words = (n_max + 63) / 64;
     unsigned long long *mask = static_cast<unsigned long long *>(workspace);
     hipStream_t s = tsod_stream(stream);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, s, boxes, stride, label_col, counts, n_max, words,
-                       iou_thr, mask);
+    if (stride == 4)
+        hipLaunchKernelGGL((nms_mask_kernel<4, -1>), dim3(words, words, B), dim3(64), 0, s, boxes, counts, n_max, words,
+                           iou_thr, mask);
+    else if (label_col >= 0)
+        hipLaunchKernelGGL((nms_mask_kernel<6, 5>), dim3(words, words, B), dim3(64), 0, s, boxes, counts, n_max, words,
+                           iou_thr, mask);
+    else
+        hipLaunchKernelGGL((nms_mask_kernel<6, -1>), dim3(words, words, B), dim3(64), 0, s, boxes, counts, n_max, words,
+                           iou_thr, mask);
     const size_t lds = (size_t)n_post * sizeof(int);
     const int wpl = (words + 63) / 64;
 #define TSOD_NMS_SCAN(W)                                                                                                \
