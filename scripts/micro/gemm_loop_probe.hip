@@ -4,6 +4,7 @@
 //   bit 1: no LDS writes in the loop (LDS keeps the first K-step; the barrier pair goes too)
 //   bit 2: no LDS fragment reads in the loop (fragments stay in registers)
 //   bit 3: no barriers around the LDS writes (racy on purpose: prices the barriers alone)
+//   bit 4: the B operand is not written to LDS in the loop (upper bound for feeding B fragments straight from global memory)
 // WAVES = 1 (one wave owns the 64x64 tile) or 4 (four waves, 32x32 each).  Results are meaningless with a switch on;
 // only the timing matters.  Build: hipcc -O3 --offload-arch=gfx950 gemm_loop_probe.hip -o probe
 #include <hip/hip_runtime.h>
@@ -43,7 +44,7 @@ probe(const float *__restrict__ A, const float *__restrict__ B, float *__restric
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
             *reinterpret_cast<float4 *>(smem + (r0 + RPP * i) * LDK + c4) = ra[i];
-            *reinterpret_cast<float4 *>(smem + BM * LDK + (r0 + RPP * i) * LDK + c4) = rb[i];
+            if (!(FLAGS & 16)) *reinterpret_cast<float4 *>(smem + BM * LDK + (r0 + RPP * i) * LDK + c4) = rb[i];
         }
     };
     f32x16 acc[TM][TN];
@@ -199,6 +200,91 @@ void run_glds(const float *A, const float *B, float *C, int M, int N, int K) {
     printf("glds, %d LDS buffers: %7.3f ms  %6.1f TF/s\n", NBUF, ms, 2.0 * M * N * K / ms / 1e9);
 }
 
+// B fragments straight from global memory: B is pre-packed in MFMA fragment order,
+//   Bf[n/32][k/32][ks (4)][lane (64)][4] = B[n = 32*(n/32) + lane%32][k = 32*(k/32) + 8*ks + 4*(lane/32) + 0..3],
+// so one wave-load is 1 KiB contiguous and B never touches LDS (no ds_write, no ds_read for it); A is staged through a
+// single LDS stage as in probe<4,0>.  FLAGS bit 0: no global loads for A in the loop (prices the B stream alone).
+template <int FLAGS>
+__global__ void __launch_bounds__(256, 6)
+probe_bdirect(const float *__restrict__ A, const float *__restrict__ Bf, float *__restrict__ C, int M, int N, int K) {
+    constexpr int TPR = BK / 4, RPP = 256 / TPR, ROWS = BM / RPP;
+    __shared__ __align__(16) float smem[BM * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = N / BN;
+    const int nwg = gridDim.x, qq = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int tile = (xcd < r8 ? xcd * (qq + 1) : r8 * (qq + 1) + (xcd - r8) * qq) + (blockIdx.x >> 3);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int c4 = (tid % TPR) * 4, r0 = tid / TPR;
+    const float *ap[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) ap[i] = A + (long)(m0 + r0 + RPP * i) * K + c4;
+    const int nk = K / BK;
+    // this wave's B stream: block row (n0 + wn*32)/32, K-steps consecutive, 4 KiB each
+    const float4 *bf = reinterpret_cast<const float4 *>(Bf) + ((long)((n0 >> 5) + wn) * nk) * 256 + lane;
+    float4 ra[ROWS];
+    auto load_a = [&](int k) {
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) ra[i] = *reinterpret_cast<const float4 *>(ap[i] + k);
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) *reinterpret_cast<float4 *>(smem + (r0 + RPP * i) * LDK + c4) = ra[i];
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const float *As = smem + (wm * 32 + (lane & 31)) * LDK + 4 * (lane >> 5);
+    float4 fb[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb[0][ks] = bf[ks * 64];
+    load_a(0);
+    store_a();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        const int cur = kt & 1, nxt = cur ^ 1;
+        float4 fa[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fa[ks] = *reinterpret_cast<const float4 *>(As + ks * 8);
+        if (more) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fb[nxt][ks] = bf[(long)(kt + 1) * 256 + ks * 64];
+            if (!(FLAGS & 1)) load_a((kt + 1) * BK);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks].x, fb[cur][ks].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks].y, fb[cur][ks].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks].z, fb[cur][ks].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks].w, fb[cur][ks].w, acc, 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) store_a();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int col = n0 + wn * 32 + (lane & 31);
+        C[(long)row * N + col] = acc[e];
+    }
+}
+
+template <int FLAGS>
+void run_bdirect(const float *A, const float *Bf, float *C, int M, int N, int K) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int grid = (M / BM) * (N / BN);
+    probe_bdirect<FLAGS><<<grid, 256>>>(A, Bf, C, M, N, K);
+    (void)hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) probe_bdirect<FLAGS><<<grid, 256>>>(A, Bf, C, M, N, K);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    ms /= 5;
+    printf("B fragments from global, no-A-global %d: %7.3f ms  %6.1f TF/s\n", FLAGS & 1, ms, 2.0 * M * N * K / ms / 1e9);
+}
+
 template <int WAVES, int FLAGS>
 void run(const float *A, const float *B, float *C, int M, int N, int K) {
     hipEvent_t e0, e1;
@@ -210,8 +296,8 @@ void run(const float *A, const float *B, float *C, int M, int N, int K) {
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     ms /= 5;
-    printf("waves %d  no-global %d no-ldswrite %d no-ldsread %d no-barrier %d : %7.3f ms  %6.1f TF/s\n", WAVES, FLAGS & 1,
-           (FLAGS >> 1) & 1, (FLAGS >> 2) & 1, (FLAGS >> 3) & 1, ms, 2.0 * M * N * K / ms / 1e9);
+    printf("waves %d  no-global %d no-ldswrite %d no-ldsread %d no-barrier %d no-B-write %d : %7.3f ms  %6.1f TF/s\n", WAVES, FLAGS & 1,
+           (FLAGS >> 1) & 1, (FLAGS >> 2) & 1, (FLAGS >> 3) & 1, (FLAGS >> 4) & 1, ms, 2.0 * M * N * K / ms / 1e9);
 }
 
 int main(int argc, char **argv) {
@@ -227,8 +313,33 @@ int main(int argc, char **argv) {
     run<1, 0>(A, B, C, M, N, K); run<1, 1>(A, B, C, M, N, K); run<1, 3>(A, B, C, M, N, K); run<1, 7>(A, B, C, M, N, K);
     run<1, 4>(A, B, C, M, N, K); run<1, 2>(A, B, C, M, N, K);
     run<4, 0>(A, B, C, M, N, K); run<4, 1>(A, B, C, M, N, K); run<4, 3>(A, B, C, M, N, K); run<4, 7>(A, B, C, M, N, K);
-    run<4, 4>(A, B, C, M, N, K); run<4, 2>(A, B, C, M, N, K); run<4, 9>(A, B, C, M, N, K); run<4, 8>(A, B, C, M, N, K);
+    run<4, 4>(A, B, C, M, N, K); run<4, 2>(A, B, C, M, N, K); run<4, 9>(A, B, C, M, N, K); run<4, 8>(A, B, C, M, N, K); run<4, 17>(A, B, C, M, N, K);
     run_glds<2>(A, B, C, M, N, K); run_glds<3>(A, B, C, M, N, K); run_glds<4>(A, B, C, M, N, K);
+    {   // B in fragment order
+        std::vector<float> hb((size_t)N * K), hf((size_t)N * K);
+        (void)hipMemcpy(hb.data(), B, hb.size() * 4, hipMemcpyDeviceToHost);
+        const int nkk = K / 32;
+        for (int nb = 0; nb < N / 32; ++nb)
+            for (int kt = 0; kt < nkk; ++kt)
+                for (int ks = 0; ks < 4; ++ks)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 4; ++e)
+                            hf[((((size_t)nb * nkk + kt) * 4 + ks) * 64 + l) * 4 + e] =
+                                hb[(size_t)(nb * 32 + (l & 31)) * K + kt * 32 + ks * 8 + 4 * (l >> 5) + e];
+        float *Bf;
+        (void)hipMalloc(&Bf, hf.size() * 4);
+        (void)hipMemcpy(Bf, hf.data(), hf.size() * 4, hipMemcpyHostToDevice);
+        run_bdirect<0>(A, Bf, C, M, N, K); run_bdirect<1>(A, Bf, C, M, N, K);
+        std::vector<float> c0((size_t)M * N), c1((size_t)M * N);
+        probe<4, 0><<<(M / BM) * (N / BN), 256>>>(A, B, C, M, N, K);
+        (void)hipMemcpy(c0.data(), C, c0.size() * 4, hipMemcpyDeviceToHost);
+        (void)hipMemset(C, 0, c0.size() * 4);
+        probe_bdirect<0><<<(M / BM) * (N / BN), 256>>>(A, Bf, C, M, N, K);
+        (void)hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost);
+        size_t bad = 0;
+        for (size_t i = 0; i < c0.size(); ++i) bad += c0[i] != c1[i];
+        printf("B-direct vs register-staged: %zu of %zu elements differ\n", bad, c0.size());
+    }
     // the DMA path must reproduce the register-staged result bit for bit (same k order per MFMA chain)
     std::vector<float> c0((size_t)M * N), c1((size_t)M * N);
     probe<4, 0><<<(M / BM) * (N / BN), 256>>>(A, B, C, M, N, K);

@@ -234,7 +234,24 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
                 }
-            if (ks == 0 && do_store) store_lds(buf ^ 1, sra, srb);
+            if (do_store) {
+                // the A_ROWS + B_ROWS LDS writes of the next step are dealt out over this step's sub-steps, one share
+                // behind each MFMA group: a 16 KB burst right after the barrier stalls the fragment reads of the
+                // other workgroups on the CU (probe: halving the burst recovers ~90 % of the LDS-write cost)
+                // the two operands' LDS writes go out behind different MFMA groups: one 16 KB burst right after the
+                // barrier stalls the fragment reads of the other workgroups on the CU (+2-4 % on the two-stage tiles)
+                constexpr int SUB = kBK / 8;
+                float *As = smem + (buf ^ 1) * STAGE;
+                float *Bs = As + BM * kLDK;
+                if (ks == 0) {
+#pragma unroll
+                    for (int q = 0; q < A_ROWS; ++q) *reinterpret_cast<float4 *>(As + (r0 + RPP * q) * kLDK + c4) = sra[q];
+                }
+                if (ks == (SUB > 2 ? 2 : SUB - 1)) {
+#pragma unroll
+                    for (int q = 0; q < B_ROWS; ++q) *reinterpret_cast<float4 *>(Bs + (r0 + RPP * q) * kLDK + c4) = srb[q];
+                }
+            }
         }
         __syncthreads();
     };
