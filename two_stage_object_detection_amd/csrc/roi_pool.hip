@@ -85,10 +85,15 @@ roi_pool_kernel(const float *__restrict__ feat, int B, int Hf, int Wf, int C, in
 }
 
 // out [B*R][out_pitch]: mean over the PH*PW bin maxima, RoIs given in image coordinates.
-__global__ void __launch_bounds__(1024)
+// A workgroup = kQuads channel quads x PH bin rows of one RoI: thread (q, ph) sums the PW bin maxima of its row (the
+// per-thread chain is PW windows instead of PH*PW), the PH row sums meet in LDS and are added in row order.
+constexpr int kQuads = 32;
+
+__global__ void __launch_bounds__(256)
 roi_pool_avg_kernel(const float *__restrict__ feat, int B, int Hf, int Wf, int C, int pitch,
                     const float *__restrict__ rois, const int *__restrict__ roi_indices, int R,
                     float img_h, float img_w, float scale, int PH, int PW, float *__restrict__ out, int out_pitch) {
+    __shared__ float4 rowsum[8][kQuads];
     const int k = blockIdx.x;
     const float4 rr = reinterpret_cast<const float4 *>(rois)[k];
     // nets/classify.py:35-36: divide by the image side, then multiply by the map side
@@ -102,9 +107,14 @@ roi_pool_avg_kernel(const float *__restrict__ feat, int B, int Hf, int Wf, int C
     const float bin_w = (float)g.rw / (float)PW;
     const float *fmap = feat + (long)g.b * Hf * Wf * pitch;
     const float nb = (float)(PH * PW);
-    for (int c4 = threadIdx.x; c4 < (C >> 2); c4 += blockDim.x) {
+    const int q = threadIdx.x % kQuads, slot = threadIdx.x / kQuads;      // slot < 8
+    const int c4 = blockIdx.y * kQuads + q;
+    const bool live = c4 < (C >> 2);
+    float4 total = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ph0 = 0; ph0 < PH; ph0 += 8) {                                  // PH <= 8: one pass
+        const int ph = ph0 + slot;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int ph = 0; ph < PH; ++ph) {
+        if (live && ph < PH) {
             int hs, he;
             bin_range(ph, bin_h, g.sh, Hf, hs, he);
             for (int pw = 0; pw < PW; ++pw) {
@@ -114,9 +124,20 @@ roi_pool_avg_kernel(const float *__restrict__ feat, int B, int Hf, int Wf, int C
                 acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
             }
         }
-        *reinterpret_cast<float4 *>(out + (long)k * out_pitch + 4 * c4) =
-            make_float4(acc.x / nb, acc.y / nb, acc.z / nb, acc.w / nb);
+        rowsum[slot][q] = acc;
+        __syncthreads();
+        if (slot == 0) {
+            const int rows = min(8, PH - ph0);
+            for (int r = 0; r < rows; ++r) {
+                const float4 v = rowsum[r][q];
+                total.x += v.x; total.y += v.y; total.z += v.z; total.w += v.w;
+            }
+        }
+        __syncthreads();
     }
+    if (slot == 0 && live)
+        *reinterpret_cast<float4 *>(out + (long)k * out_pitch + 4 * c4) =
+            make_float4(total.x / nb, total.y / nb, total.z / nb, total.w / nb);
 }
 
 }  // namespace
@@ -142,10 +163,8 @@ extern "C" int tsod_roi_pool_avg_f32(const float *feat, int32_t B, int32_t Hf, i
     TSOD_REQUIRE((C & 3) == 0 && (feat_pitch & 3) == 0 && feat_pitch >= C && (out_pitch & 3) == 0 && out_pitch >= C,
                  TSOD_ERR_ALIGNMENT);
     TSOD_REQUIRE(tsod_aligned16(feat) && tsod_aligned16(rois) && tsod_aligned16(out), TSOD_ERR_ALIGNMENT);
-    // one channel quad per thread where possible: the per-RoI work is a serial chain of window reads
-    int threads = ((C / 4 + 63) / 64) * 64;
-    threads = threads < 64 ? 64 : (threads > 1024 ? 1024 : threads);
-    hipLaunchKernelGGL(roi_pool_avg_kernel, dim3(B * R), dim3(threads), 0, tsod_stream(stream), feat, B, Hf, Wf, C,
+    const int quads = C / 4;
+    hipLaunchKernelGGL(roi_pool_avg_kernel, dim3(B * R, (quads + kQuads - 1) / kQuads), dim3(256), 0, tsod_stream(stream), feat, B, Hf, Wf, C,
                        feat_pitch, rois, roi_indices, R, img_h, img_w, spatial_scale, PH, PW, out, out_pitch);
     return tsod_launch_status();
 }
