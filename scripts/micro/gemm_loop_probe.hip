@@ -11,13 +11,17 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 64, BN = 64, BK = 32, LDK = BK + 4;
 
 template <int WAVES, int FLAGS>
 __global__ void __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : 6)
-probe(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, int K) {
+probe(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, int K,
+      long long *__restrict__ stamps = nullptr) {
+    long long c0 = 0, r0s = 0;
+    if (stamps && threadIdx.x == 0) { c0 = __builtin_amdgcn_s_memtime(); r0s = __builtin_amdgcn_s_memrealtime(); }
     constexpr int THREADS = 64 * WAVES, TPR = BK / 4, RPP = THREADS / TPR, ROWS = BM / RPP;
     constexpr int WM = WAVES == 1 ? 64 : 32, WN = WM, TM = WM / 32, TN = WN / 32;
     __shared__ __align__(16) float smem[(BM + BN) * LDK];
@@ -99,6 +103,10 @@ probe(const float *__restrict__ A, const float *__restrict__ B, float *__restric
             if (more) store_lds();
             if (!(FLAGS & 8)) __syncthreads();
         }
+    }
+    if (stamps && threadIdx.x == 0) {       // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+        stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
+        stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0s;
     }
     // plain column-per-lane store (not part of the question)
 #pragma unroll
@@ -315,6 +323,24 @@ int main(int argc, char **argv) {
     run<4, 0>(A, B, C, M, N, K); run<4, 1>(A, B, C, M, N, K); run<4, 3>(A, B, C, M, N, K); run<4, 7>(A, B, C, M, N, K);
     run<4, 4>(A, B, C, M, N, K); run<4, 2>(A, B, C, M, N, K); run<4, 9>(A, B, C, M, N, K); run<4, 8>(A, B, C, M, N, K); run<4, 17>(A, B, C, M, N, K);
     run_glds<2>(A, B, C, M, N, K); run_glds<3>(A, B, C, M, N, K); run_glds<4>(A, B, C, M, N, K);
+    {   // in-kernel clock of three loop bodies after ~1 s of back-to-back launches each
+        const int grid = (M / BM) * (N / BN);
+        long long *st;
+        (void)hipMalloc(&st, (size_t)grid * 16);
+        std::vector<long long> h((size_t)grid * 2);
+        auto clock_of = [&](const char *what, auto launch) {
+            for (int r = 0; r < 600; ++r) launch();
+            (void)hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+            std::vector<double> c;
+            for (int i = 0; i < grid; ++i) if (h[2 * i + 1] > 0) c.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 100e6);
+            std::sort(c.begin(), c.end());
+            printf("in-kernel clock, %-46s %.2f GHz (median over %zu workgroups)\n", what, c[c.size() / 2] / 1e9, c.size());
+        };
+        clock_of("MFMA only (no global, no LDS write/read):", [&] { probe<4, 7><<<grid, 256>>>(A, B, C, M, N, K, st); });
+        clock_of("MFMA + LDS fragment reads:", [&] { probe<4, 3><<<grid, 256>>>(A, B, C, M, N, K, st); });
+        clock_of("MFMA + LDS reads + writes + barriers:", [&] { probe<4, 1><<<grid, 256>>>(A, B, C, M, N, K, st); });
+        clock_of("everything (global loads too):", [&] { probe<4, 0><<<grid, 256>>>(A, B, C, M, N, K, st); });
+    }
     {   // B in fragment order
         std::vector<float> hb((size_t)N * K), hf((size_t)N * K);
         (void)hipMemcpy(hb.data(), B, hb.size() * 4, hipMemcpyDeviceToHost);

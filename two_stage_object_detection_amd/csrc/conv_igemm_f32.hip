@@ -84,6 +84,13 @@ __device__ __forceinline__ int seg_channel(const ConvParams &p, int ci) {
 // so more workgroups share a CU (more waves per SIMD to cover each other's waits, finer-grained chip filling).
 // BK = floats per K-step (32 or 64): LDS rows are BK + 4 floats (pitch = 4 mod 64 banks: every 16-lane group of
 // ds_read_b128 hits 16 distinct 4-bank slots); a longer step halves the barriers per FLOP of long-K (3x3) layers.
+#ifdef TSOD_CLOCK_DIAG
+// Diagnostic build only (make diag -> libtsod_diag.so): thread 0 of every workgroup stamps s_memtime (core clock) and
+// s_memrealtime (100 MHz) around its K loop; clock = d(memtime) / d(memrealtime) * 100 MHz (scripts/conv_clock.py).
+// The stamps go to a buffer of their own and nothing is computed from them.
+__device__ long long *g_clock_buf = nullptr;
+#endif
+
 template <int BM, int BN, int WM, int WN, int MIN_WAVES, int NBUF = 2, int BK = 32>
 __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_igemm_kernel(const ConvParams p) {
     constexpr int kBK = BK, kLDK = BK + 4;
@@ -257,6 +264,10 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     };
 
     const int nk = kt_end - kt_begin;
+#ifdef TSOD_CLOCK_DIAG
+    long long diag_c0 = 0, diag_r0 = 0;
+    if (g_clock_buf != nullptr && tid == 0) { diag_c0 = __builtin_amdgcn_s_memtime(); diag_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     if (NBUF == 1) {
         if (nk > 0) {
             load_global(ra0, rb0);
@@ -285,6 +296,12 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
         }
     }
 
+#ifdef TSOD_CLOCK_DIAG
+    if (g_clock_buf != nullptr && tid == 0 && blockIdx.x < 32768) {
+        g_clock_buf[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - diag_c0;
+        g_clock_buf[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - diag_r0;
+    }
+#endif
     // ---- epilogue.  acc[i][j][e]: column = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (m).
     // All global accesses go through buffer descriptors: rows / columns outside the problem get the
     // out-of-range offset, so there is no per-element branch (loads return 0, stores are dropped), and the
@@ -717,3 +734,8 @@ extern "C" int tsod_pack_conv_weight_f32(const float *w_oihw, int32_t Cout, int3
     return tsod_launch_status();
 }
 
+#ifdef TSOD_CLOCK_DIAG
+extern "C" int tsod_debug_set_clock_buf(long long *buf /* device, 2 * 32768 int64, or NULL */) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_clock_buf), &buf, sizeof(buf)) == hipSuccess ? TSOD_OK : TSOD_ERR_LAUNCH;
+}
+#endif
