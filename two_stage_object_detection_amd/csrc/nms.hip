@@ -117,11 +117,31 @@ nms_scan_kernel(const float *__restrict__ boxes, int stride, const int *__restri
             const int w = lane + 64 * s;
             if (w < words && w > blk) {
                 unsigned long long acc = 0;
+                const unsigned long long *col = mrow + (long)blk * 64 * words + w;
+                if (__popcll(kept) >= 32) {
+                    // most of the block survived: sweep all 64 rows, 16 loads in flight
 #pragma unroll 16
-                for (int bit = 0; bit < 64; ++bit) {
-                    const int r = blk * 64 + bit;
-                    const unsigned long long v = r < n ? mrow[(long)r * words + w] : 0ull;
-                    acc |= ((kept >> bit) & 1ull) ? v : 0ull;
+                    for (int bit = 0; bit < 64; ++bit) {
+                        const int r = blk * 64 + bit;
+                        const unsigned long long v = r < n ? col[(long)bit * words] : 0ull;
+                        acc |= ((kept >> bit) & 1ull) ? v : 0ull;
+                    }
+                } else {
+                    // few survivors: only their rows matter - walk the set bits of `kept` (wave-uniform), eight rows
+                    // in flight per round
+                    unsigned long long k = kept;
+                    while (k) {
+                        int b[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            b[q] = k ? __ffsll((long long)k) - 1 : -1;
+                            k &= k - 1;                   // 0 stays 0
+                        }
+                        unsigned long long v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = b[q] >= 0 ? col[(long)b[q] * words] : 0ull;
+                        acc |= ((v[0] | v[1]) | (v[2] | v[3])) | ((v[4] | v[5]) | (v[6] | v[7]));
+                    }
                 }
                 removed[s] |= acc;
             }
