@@ -7,7 +7,7 @@ consecutive requests round-robin on ``depth`` HIP streams, so the tail of one fo
 Every request still executes the whole path; nothing is shared between slots but the (read-only) weights.
 
 This is what ``bench.py`` measures by default (``--in-flight 4``): ~585 images/s against ~420 strictly serial at batch 1
-on MI355X.  Two streams give nothing (they share a hardware queue); 3-8 are equivalent.
+on MI355X.  Depth 2 already gives ~540; depths 3-8 are equivalent.
 """
 from __future__ import annotations
 
