@@ -178,7 +178,8 @@ int tsod_loc2bbox_f32(const float *src, const float *loc, int64_t n, float *out,
  *   idx[b][k]      = source index of the k-th best, k < n_sel; -1 beyond    (int32, [B][n_pre])
  *   boxes_out[b][k]= boxes[b][idx] (zeros beyond n_sel)                     ([B][n_pre][4]) (may be NULL)
  *   keys_out[b][k] = keys[b][idx]  (-inf beyond n_sel)                      ([B][n_pre])    (may be NULL)
- * n_pre <= 16384, n <= 81920.  One workgroup per image, keys held in registers, LDS radix-select + bitonic sort. */
+ * n_pre <= 16384.  One workgroup per image, LDS radix-select + bitonic sort; rows of up to 81920 keys are held in
+ * registers after one pass over memory, longer rows are re-read per pass. */
 int tsod_sort_topk_desc_f32(const float *keys, const float *boxes, int32_t B, int32_t n, int32_t n_pre,
                             int32_t *counts, int32_t *idx, float *boxes_out, float *keys_out,
                             tsod_stream_t stream);

@@ -160,6 +160,21 @@ def test_proposal_creator_single_image_surface(dev):
         ProposalCreator("training")(loc[:40].to(dev), score[:40].to(dev), anchor[:40].to(dev), (3, 320, 448))
 
 
+def test_proposal_layer_on_a_very_large_map(dev):
+    """142 272 anchors (a 1664x2432 image at stride 16): more keys than the top-k kernel holds in registers, so the
+    streaming form of the selection runs; same RoIs as the oracle."""
+    from two_stage_object_detection_amd.nets.rpn import ProposalCreator
+    g = torch.Generator().manual_seed(6)
+    anchor = oracle.enumerate_shifted_anchor(oracle.generate_basic_anchor(), 16, 104, 152)
+    assert anchor.shape[0] == 142272
+    loc = torch.randn(anchor.shape[0], 4, generator=g) * 0.3
+    score = torch.rand(anchor.shape[0], generator=g)
+    ref = oracle.proposal_layer(loc, score, anchor, (3, 1664, 2432), mode="training")
+    got = ProposalCreator("training")(loc.to(dev), score.to(dev), anchor.to(dev), (3, 1664, 2432), 1.0)
+    assert got.shape == ref.shape == (300, 4)
+    assert (got.cpu() - ref).abs().max().item() < 1e-3
+
+
 # ----------------------------------------------------------------------------- end to end
 @pytest.mark.parametrize("backbone,shape,ncls", [("resnet50", (2, 3, 320, 448), 20), ("hardnet39", (2, 3, 320, 448), 20),
                                                  ("hardnet68", (1, 3, 256, 320), 20), ("resnet50", (1, 3, 800, 1333), 80),

@@ -230,7 +230,8 @@ def test_rpn_decode(ops, dev, B, Hf, Wf, stride):
 
 
 @pytest.mark.parametrize("B,n,n_pre", [(1, 9450, 3000), (2, 37800, 3000), (1, 37800, 12000), (3, 500, 3000), (2, 4096, 64),
-                                      (1, 9450, 2000), (2, 20000, 6000), (1, 70000, 16384)])
+                                      (1, 9450, 2000), (2, 20000, 6000), (1, 70000, 16384),
+                                      (1, 200000, 3000), (2, 100000, 12000)])     # > 81920 keys: the streaming kernel
 def test_sort_topk_exact(ops, dev, B, n, n_pre):
     g = torch.Generator().manual_seed(13)
     keys = torch.rand(B, n, generator=g)

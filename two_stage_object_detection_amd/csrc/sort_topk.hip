@@ -246,6 +246,111 @@ sort_topk_kernel(const float *__restrict__ keys, const float *__restrict__ boxes
     }
 }
 
+// Same selection for key rows too long to hold in registers (n > 80 * 1024): every pass re-reads the keys from global
+// memory (six sweeps of an L2-resident row), plain LDS histogram atomics, ties always compacted in index order.
+__global__ void __launch_bounds__(kThreads)
+sort_topk_stream_kernel(const float *__restrict__ keys, const float *__restrict__ boxes, int n, int n_pre,
+                        int *__restrict__ counts, int *__restrict__ idx_out, float *__restrict__ boxes_out,
+                        float *__restrict__ keys_out) {
+    extern __shared__ __align__(16) unsigned long long sm[];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned wave_tot[kThreads / 64];
+    __shared__ unsigned s_prefix, s_need, s_nvalid, s_lt, s_eq_base;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.x;
+    const float *k = keys + (long)b * n;
+    if (tid == 0) { s_nvalid = 0; s_lt = 0; s_eq_base = 0; s_prefix = 0; }
+    __syncthreads();
+    {
+        unsigned local = 0;
+        for (int i = tid; i < n; i += kThreads) local += desc_key(k[i]) < kDNegInf ? 1u : 0u;
+        for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
+        if (lane == 0 && local) atomicAdd(&s_nvalid, local);
+    }
+    __syncthreads();
+    const int n_sel = min((int)s_nvalid, n_pre);
+    if (tid == 0) { counts[b] = n_sel; s_need = (unsigned)n_sel; }
+    __syncthreads();
+    if (n_sel > 0) {
+        unsigned mask = 0;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = s_prefix;
+            for (int i = tid; i < n; i += kThreads) {
+                const unsigned d = desc_key(k[i]);
+                if ((d & mask) == prefix) atomicAdd(&hist[(d >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            const unsigned mine = tid < 256 ? hist[tid] : 0u;
+            unsigned incl = mine;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned v = __shfl_up(incl, off);
+                if (lane >= off) incl += v;
+            }
+            if (lane == 63 && wid < 4) wave_tot[wid] = incl;
+            __syncthreads();
+            for (int w = 0; w < wid && w < 4; ++w) incl += wave_tot[w];
+            const unsigned need = s_need;
+            const unsigned excl = incl - mine;
+            __syncthreads();
+            if (tid < 256 && excl < need && need <= incl) {
+                s_prefix = prefix | ((unsigned)tid << shift);
+                s_need = need - excl;
+            }
+            mask |= 0xFFu << shift;
+            __syncthreads();
+        }
+        const unsigned T = s_prefix;
+        const unsigned need_eq = s_need;
+        const unsigned count_lt = (unsigned)n_sel - need_eq;
+        // d < T: any slot in [0, count_lt) (the sort fixes the order); d == T: slot count_lt + rank among equals in index order
+        for (int base = 0; base < n; base += kThreads) {
+            const int i = base + tid;
+            const unsigned d = i < n ? desc_key(k[i]) : 0xFFFFFFFFu;
+            if (i < n && d < T) sm[atomicAdd(&s_lt, 1u)] = ((unsigned long long)d << 32) | (unsigned)i;
+            const bool is_eq = (i < n) && (d == T);
+            const unsigned long long bal = __ballot(is_eq);
+            if (lane == 0) wave_tot[wid] = (unsigned)__popcll(bal);
+            __syncthreads();
+            unsigned before = s_eq_base, total = 0;
+            for (int w = 0; w < kThreads / 64; ++w) {
+                const unsigned t = wave_tot[w];
+                if (w < wid) before += t;
+                total += t;
+            }
+            const unsigned rank = before + __popcll(bal & ((1ull << lane) - 1ull));
+            if (is_eq && rank < need_eq) sm[count_lt + rank] = ((unsigned long long)d << 32) | (unsigned)i;
+            __syncthreads();
+            if (tid == 0) s_eq_base += total;
+            __syncthreads();
+        }
+        int S = kThreads;
+        while (S < n_sel) S <<= 1;
+        for (int i = n_sel + tid; i < S; i += kThreads) sm[i] = ~0ull;
+        __syncthreads();
+        switch (S / kThreads) {
+            case 1: block_bitonic<1>(sm, tid); break;
+            case 2: block_bitonic<2>(sm, tid); break;
+            case 4: block_bitonic<4>(sm, tid); break;
+            case 8: block_bitonic<8>(sm, tid); break;
+            default: block_bitonic<16>(sm, tid); break;
+        }
+    }
+    for (int r = tid; r < n_pre; r += kThreads) {
+        int src = -1;
+        if (r < n_sel) src = (int)(unsigned)(sm[r] & 0xFFFFFFFFull);
+        idx_out[(long)b * n_pre + r] = src;
+        if (boxes_out != nullptr) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src >= 0) v = reinterpret_cast<const float4 *>(boxes)[(long)b * n + src];
+            reinterpret_cast<float4 *>(boxes_out)[(long)b * n_pre + r] = v;
+        }
+        if (keys_out != nullptr) keys_out[(long)b * n_pre + r] = src >= 0 ? k[src] : -INFINITY;
+    }
+}
+
 }  // namespace
 
 extern "C" int tsod_sort_topk_desc_f32(const float *keys, const float *boxes, int32_t B, int32_t n, int32_t n_pre,
@@ -253,7 +358,7 @@ extern "C" int tsod_sort_topk_desc_f32(const float *keys, const float *boxes, in
                                        tsod_stream_t stream) {
     TSOD_REQUIRE(keys && counts && idx, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(B > 0 && n > 0 && n_pre > 0, TSOD_ERR_INVALID_ARG);
-    TSOD_REQUIRE(n_pre <= 16384 && n <= 80 * kThreads, TSOD_ERR_UNSUPPORTED);
+    TSOD_REQUIRE(n_pre <= 16384, TSOD_ERR_UNSUPPORTED);
     TSOD_REQUIRE(boxes_out == nullptr || boxes != nullptr, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE((boxes == nullptr || tsod_aligned16(boxes)) && (boxes_out == nullptr || tsod_aligned16(boxes_out)),
                  TSOD_ERR_ALIGNMENT);
@@ -271,6 +376,17 @@ extern "C" int tsod_sort_topk_desc_f32(const float *keys, const float *boxes, in
         hipLaunchKernelGGL(sort_topk_kernel<KPT>, dim3(B), dim3(kThreads), lds, tsod_stream(stream), keys, boxes, n,  \
                            n_pre, P, counts, idx, boxes_out, keys_out);                                                \
     } while (0)
+    if (n > 80 * kThreads) {
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(sort_topk_stream_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return TSOD_ERR_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL(sort_topk_stream_kernel, dim3(B), dim3(kThreads), lds, tsod_stream(stream), keys, boxes, n,
+                           n_pre, counts, idx, boxes_out, keys_out);
+        return tsod_launch_status();
+    }
     if (n <= 10 * kThreads) TSOD_SORT(10);
     else if (n <= 20 * kThreads) TSOD_SORT(20);
     else if (n <= 40 * kThreads) TSOD_SORT(40);
