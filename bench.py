@@ -2,24 +2,40 @@
 """bench.py -- images/sec of the full Faster R-CNN ResNet-50 inference forward on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one detector forward (NCHW->NHWC, 53 conv GEMMs, max pool, RPN convs + decode + top-k +
-NMS + pad, fused RoI pool + mean, 2 linears, detection records) over one batch of synthetic
-3x800x1333 images that is already resident in HBM, plus - for N > 1 - the RCCL all-gather of the
-[B,300,6] detection records.  Each step is one HIP-graph launch; consecutive steps are issued round-robin
-on --in-flight HIP streams (default 4, each with its own graph + buffers), i.e. a batch-1 server with
-several requests in flight: the tail of one forward overlaps the next one's kernels.  --in-flight 1 gives the
-strictly serial number; the single-stream latency of one forward is reported as latency_ms_single_stream.  Workload at N=1 = BASELINE.json configs[1] (batch 1).  Weak scaling:
-every rank processes its own batch; value = images of all ranks / max-over-ranks time.
+With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: it starts N rank processes
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a child, before any GPU
+call of its own) and exits with their code; under torchrun (WORLD_SIZE set) it is a rank.  One rank per GPU, backend
+"nccl" (= RCCL over xGMI).
 
-The JSON line also carries
-  roofline     : f32-MFMA roofline of the dominant kernel family (conv_igemm_kernel, all launches of one
-                 forward): algorithmic FLOPs / HIP-event time of those launches, vs 157.3 TFLOP/s.
-                 roofline.traffic = HBM bytes per conv launch from the FETCH_SIZE / WRITE_SIZE counters, collected
-                 by two short `rocprofv3 --pmc` child runs of this script (rank 0, N=1; --no-pmc skips them).
-  cpu_baseline : the CPU oracle (torch CPU ops + C nms/roi_pool restatement of the reference's path)
-                 timed on this box's host cores on the same workload (rank 0, N=1 only).
+A step = one detector forward (NCHW->NHWC, 53 conv GEMMs, max pool, fused RPN conv + decode + top-k + NMS + pad, fused
+RoI pool + mean, fused head GEMM, detection records) over one batch of synthetic 3x800x1333 images already resident in
+HBM, plus - for N > 1 - the RCCL all-gather of the [B,300,6] detection records.  Each step is one HIP-graph launch.
+
+Workloads: N = 1 -> BASELINE.json configs[1] (batch 1); N > 1 -> configs[4] (data-parallel, batch 8 per rank: 64 images
+over 8 GPUs), weak scaling: every rank processes its own images, value = images of all ranks / max-over-ranks time.
+`--batch` overrides the per-rank batch.
+
+Two schedules are measured and BOTH are reported in the one JSON line:
+  * serial     : one forward at a time on one stream (`serial`: images/s, ms per step = latency of a forward).  The
+                 `roofline` object belongs to this schedule: algorithmic conv FLOPs / per-kernel HIP-event time of the
+                 conv launches (on their launch stream) with the tile table tuned for it; its
+                 kernel_ms_per_forward is <= serial.ms_per_step, the step it is part of.
+  * in flight  : consecutive steps issued round-robin on --in-flight HIP streams (default 4, each with its own graph,
+                 buffers and scratch): a batch-1 server with several requests in flight, the tail of one forward
+                 overlapping the next one's kernels.  `value` / `ms_per_step` are this schedule's (with --in-flight 1
+                 they are the serial numbers); `throughput_mode` gives its whole-step bound
+                 (conv FLOPs per step / ms_per_step vs the f32-MFMA peak) - per-kernel times do not exist for
+                 overlapped kernels.
+Every timed region (exactly K steps between barrier + synchronize on both sides, max over ranks) is repeated
+--repeats times (default 5); the median repeat is reported, min / max alongside.
+
+  roofline.traffic : HBM bytes per conv launch from FETCH_SIZE / WRITE_SIZE, collected by two short `rocprofv3 --pmc`
+                     child runs of this script (rank 0, N = 1; --no-pmc skips them).
+  cpu_baseline     : the CPU oracle (torch CPU ops + C nms / roi_pool restatement of the reference's path) timed on this
+                     box's host cores on the same workload (rank 0, N = 1 only).
+  --check          : (N > 1) the gathered [N*B,300,6] records of the last step are compared on rank 0 with single-GPU
+                     forwards of every rank's images (boxes / scores <= 1e-3, classes bit-exact); a mismatch fails the run.
 """
 import argparse
 import json
@@ -35,39 +51,60 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+R_POST = 300
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (configs[1] = 1, configs[2] = 16)")
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the K-step timed region is repeated (median reported)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default: 1 at --gpus 1 = configs[1]; "
+                    "8 at --gpus > 1 = configs[4], 64 images over 8 GPUs; 16 = configs[2])")
     ap.add_argument("--backbone", default="resnet50")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--num-classes", type=int, default=80)
     ap.add_argument("--no-autotune", action="store_true")
-    ap.add_argument("--autotune-concurrent", type=int, default=None, help="time autotune candidates as this many copies in "
-                    "flight on separate streams (default: 2 when --in-flight > 1, else 1)")
     ap.add_argument("--autotune-splits", default=None, help="comma list restricting the K-slice candidates of the autotuner")
-    ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--in-flight", type=int, default=4, help="steps in flight: consecutive steps are issued round-robin on this "
                     "many HIP streams, each with its own graph and buffers (request-level pipelining of a batch-1 server)")
-    ap.add_argument("--tiles-file", default=None, help="JSON cache of autotuned (tile, split) choices: loaded if present, "
-                                                       "else written after autotuning (keeps profiler runs free of tuning launches)")
+    ap.add_argument("--tiles-file", default=None, help="JSON cache of the autotuned (tile, split) tables {'serial': [...], "
+                    "'in_flight': [...]}: loaded if present, else written after autotuning (keeps profiler runs free of "
+                    "tuning launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs behind roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-reps", type=int, default=8)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--check", action="store_true", help="N > 1: compare the gathered records with single-GPU forwards on rank 0")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the real path) | gloo (rehearsal of "
                     "the N>1 control flow on a box with fewer GPUs than ranks: ranks share devices, gather goes through host)")
-    return ap.parse_args()
+    ap.add_argument("--rehearse-cpu", action="store_true", help="launcher / rendezvous / gather / timing / --check control flow "
+                    "with fabricated records and NO GPU work (gloo; for the CPU test of the N>1 path - never a measurement)")
+    return ap.parse_args(argv)
 
 
+# ----------------------------------------------------------------------------------------------- launcher
+def launch_ranks(args, argv):
+    """--gpus N > 1 outside torchrun: start the N ranks as a child job and exit with its code.  Nothing in this process has
+    touched the GPU (importing torch does not); the ranks are fresh interpreters."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ----------------------------------------------------------------------------------------------- measurements
 def conv_event_times(plan, reps=5):
-    """HIP-event duration of every conv_igemm launch of the plan (ms), on the launch stream."""
+    """HIP-event duration of every conv launch of the plan (ms), on the launch stream."""
     from two_stage_object_detection_amd._ffi import lib, stream_ptr
     L = lib()
     out = []
@@ -125,7 +162,7 @@ def pmc_child(args, dev):
     with torch.inference_mode():
         plan = model.extractor._plan_for(x)                 # packs weights, launches no conv
         if args.tiles_file and os.path.exists(args.tiles_file):
-            plan.import_tiles(json.load(open(args.tiles_file)))
+            plan.import_tiles(json.load(open(args.tiles_file))["serial"])
         torch.cuda.synchronize()
         L, s = lib(), stream_ptr()
         for _ in range(2):                                  # pass 1 warms caches / code objects, pass 2 is the sample
@@ -134,7 +171,7 @@ def pmc_child(args, dev):
         torch.cuda.synchronize()
 
 
-def pmc_traffic(args, plan, n_launches):
+def pmc_traffic(args, tiles, n_launches):
     """HBM bytes per conv launch from rocprofv3's FETCH_SIZE / WRITE_SIZE (KiB; separate passes: both do not fit
     the TCC counter budget at once).  gfx950 tallies a wide coalesced read at half its size, so reads are doubled
     (MI355X_MICROARCH.md, HBM section).  Returns (bytes_per_launch or None, note)."""
@@ -148,8 +185,8 @@ def pmc_traffic(args, plan, n_launches):
         return None, "rocprofv3 not found"
     work = tempfile.mkdtemp(prefix="tsod_pmc_", dir="/tmp")
     try:
-        tiles = os.path.join(work, "tiles.json")
-        json.dump(plan.export_tiles(), open(tiles, "w"))
+        tiles_path = os.path.join(work, "tiles.json")
+        json.dump({"serial": tiles}, open(tiles_path, "w"))
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             env.pop(k, None)
@@ -157,7 +194,7 @@ def pmc_traffic(args, plan, n_launches):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(work, counter)
             cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
-                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--tiles-file", tiles,
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--tiles-file", tiles_path,
                    "--backbone", args.backbone, "--batch", str(args.batch), "--height", str(args.height),
                    "--width", str(args.width), "--num-classes", str(args.num_classes)]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
@@ -179,8 +216,79 @@ def pmc_traffic(args, plan, n_launches):
         shutil.rmtree(work, ignore_errors=True)
 
 
-def main():
-    args = parse()
+class Timer:
+    """The contract's timed region: exactly K steps between barrier + synchronize on both sides, max over ranks;
+    repeated R times."""
+
+    def __init__(self, world, sync, reduce_device):
+        self.world, self.sync, self.reduce_device = world, sync, reduce_device
+
+    def region(self, step, steps):
+        self.sync()
+        if self.world > 1:
+            dist.barrier()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.sync()
+        if self.world > 1:
+            dist.barrier()
+        self.sync()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.reduce_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def measure(self, step, steps, warmup, repeats):
+        for _ in range(max(warmup, 1)):
+            step()
+        ts = sorted(self.region(step, steps) for _ in range(max(1, repeats)))
+        per = [t / steps * 1e3 for t in ts]
+        return {"ms_per_step": statistics.median(per), "min": per[0], "max": per[-1], "n": len(per), "steps": steps}
+
+
+def compare_records(got, ref, atol=1e-3):
+    """[n,300,6] records: class column bit-exact, box / score columns within atol, row for row."""
+    cls_equal = bool(torch.equal(got[..., 5], ref[..., 5]))
+    err = float((got[..., :5] - ref[..., :5]).abs().max())
+    return {"ok": cls_equal and err <= atol, "classes_equal": cls_equal, "max_abs_box_score": err, "images": int(got.shape[0])}
+
+
+# ----------------------------------------------------------------------------------------------- rehearsal (no GPU)
+def rehearse_cpu(args, rank, world):
+    """The N>1 control flow on CPU ranks (gloo): same barrier / timed loop / gather / max-over-ranks / --check code as
+    the real run, with fabricated detection records instead of forwards.  Exists for tests/test_dist_gloo.py."""
+    from two_stage_object_detection_amd.dist import all_gather_detections, shard_range
+    B = args.batch
+    lo, hi = shard_range(world * B, rank, world)
+    det = torch.stack([torch.full((R_POST, 6), float(g)) for g in range(lo, hi)])
+    gathered = torch.empty((world * B, R_POST, 6))
+    timer = Timer(world, lambda: None, "cpu")
+    res = timer.measure(lambda: all_gather_detections(det, out=gathered), args.steps, args.warmup, args.repeats)
+    check = None
+    if args.check:
+        ref = torch.stack([torch.full((R_POST, 6), float(g)) for g in range(world * B)])
+        check = compare_records(gathered, ref)
+    if rank == 0:
+        line = {"metric": "rehearsal of the N>1 control flow (no GPU work, not a measurement)", "value": None,
+                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(res["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "rehearsal", "rehearsal": True,
+                "config": {"workload": "fabricated [B,300,6] records", "global_batch": world * B, "parallelism": f"dp{world}",
+                           "collective": f"all_gather_into_tensor [{world * B},300,6] f32 (gloo)"}, "check": check}
+        print(json.dumps(line), flush=True)
+    return 0 if (check is None or check["ok"]) else 3
+
+
+# ----------------------------------------------------------------------------------------------- rank body
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -188,13 +296,32 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world != args.gpus and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
-    n_gpus = world if world > 1 else 1
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the package has no CPU path)"
-    dev_index = local_rank % torch.cuda.device_count()
+    n_gpus = world
+    if args.batch is None:
+        args.batch = 8 if world > 1 else 1
+    B = args.batch
+
+    if args.rehearse_cpu:
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        rc = rehearse_cpu(args, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(rc)
+
+    n_dev = torch.cuda.device_count()                     # does not initialise the GPU
+    if n_dev == 0:
+        sys.exit("bench.py needs a GPU (the package has no CPU path)")
+    if world > 1 and args.dist_backend == "nccl" and n_dev < world:
+        sys.exit(f"bench.py: {world} ranks but only {n_dev} visible GPU(s): RCCL needs one GPU per rank "
+                 f"(use --dist-backend gloo to rehearse the control flow on fewer GPUs)")
+    dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    nccl = args.dist_backend == "nccl"
     if world > 1:
-        if args.dist_backend == "nccl":
+        if nccl:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
@@ -205,115 +332,129 @@ def main():
 
     from two_stage_object_detection_amd import hip_ops
     from two_stage_object_detection_amd.dist import all_gather_detections
+    from two_stage_object_detection_amd.serving import InFlightDetector
     from two_stage_object_detection_amd.testing import synthetic_detector
 
     model, sd = synthetic_detector(args.backbone, num_classes=args.num_classes, seed=0)
     model = model.to(dev).eval()
-    B = args.batch
-    x_cpu = torch.rand(B, 3, args.height, args.width, generator=torch.Generator().manual_seed(1234 + rank))
+
+    def images(r):
+        return torch.rand(B, 3, args.height, args.width, generator=torch.Generator().manual_seed(1234 + r))
+    x_cpu = images(rank)
     x = x_cpu.to(dev)
+    n_fly = max(1, args.in_flight)
+    timer = Timer(world, torch.cuda.synchronize, dev if nccl else "cpu")
 
     with torch.inference_mode():
         model(x)                                                       # builds the plan
         torch.cuda.synchronize()
         plan = model.extractor._plan_for(x)
+        default_tiles = plan.export_tiles()
+        tiles = {"serial": default_tiles, "in_flight": default_tiles}
         if args.tiles_file and os.path.exists(args.tiles_file):
-            plan.import_tiles(json.load(open(args.tiles_file)))
+            tiles = json.load(open(args.tiles_file))
         elif not args.no_autotune:
-            plan.autotune(verbose=args.verbose and rank == 0,
-                          splits=[int(v) for v in args.autotune_splits.split(",")] if args.autotune_splits else None,
-                          concurrent=args.autotune_concurrent if args.autotune_concurrent
-                          else (2 if (args.in_flight > 1 and not args.no_graph) else 1))
+            splits = [int(v) for v in args.autotune_splits.split(",")] if args.autotune_splits else None
+            plan.autotune(verbose=args.verbose and rank == 0, splits=splits, concurrent=1)
+            tiles["serial"] = plan.export_tiles()
+            if n_fly > 1:                                              # objective of an overlapped server: two copies in flight
+                plan.autotune(verbose=False, splits=splits, concurrent=2)
+                tiles["in_flight"] = plan.export_tiles()
+            else:
+                tiles["in_flight"] = tiles["serial"]
             if args.tiles_file and rank == 0:
-                json.dump(plan.export_tiles(), open(args.tiles_file, "w"))
-        conv_ms = conv_event_times(plan)
-        conv_flops = sum(st.flops for st in plan.conv_steps)
-        R_post = model.rpn.proposal_layer.counts()[1]
-        gathered = [torch.empty((world * B, R_post, 6), dtype=torch.float32, device=dev if args.dist_backend == "nccl" else "cpu")
-                    for _ in range(max(1, args.in_flight))] if world > 1 else None
-        if args.no_graph:
-            def step():
-                outs = model(x)
-                det = hip_ops.detections(outs[0], outs[1], outs[2])
-                if world > 1:
-                    all_gather_detections(det if args.dist_backend == "nccl" else det.cpu(), out=gathered[0])
-                return det
-        else:
-            from two_stage_object_detection_amd.serving import InFlightDetector
-            n_fly = max(1, args.in_flight)
-            server = InFlightDetector(model, x, depth=n_fly, tiles=plan.export_tiles())   # one graph + buffers per slot
-            runners = server._run
+                json.dump(tiles, open(args.tiles_file, "w"))
 
+        gathered = [torch.empty((world * B, R_POST, 6), dtype=torch.float32, device=dev if nccl else "cpu")
+                    for _ in range(n_fly)] if world > 1 else None
+
+        def make_step(server, depth):
             def step():
                 if world > 1:                           # the gather of step i is ordered behind step i on ITS stream
-                    slot = server._next % n_fly
+                    slot = server._next % depth
                     return server.submit(after=lambda outs: all_gather_detections(
-                        outs[4] if args.dist_backend == "nccl" else outs[4].cpu(), out=gathered[slot]))
+                        outs[4] if nccl else outs[4].cpu(), out=gathered[slot]))
                 return server.submit()
-        def full_step():
-            return step()
+            return step
 
-        # single-stream latency of one forward (informational; the timed region below is the K-step throughput run)
-        latency_ms = None
-        if not args.no_graph:
-            for _ in range(3):
-                runners[0]()
-            torch.cuda.synchronize()
-            t_l = time.perf_counter()
-            for _ in range(20):
-                runners[0]()
-            torch.cuda.synchronize()
-            latency_ms = (time.perf_counter() - t_l) / 20 * 1e3
-        for _ in range(max(args.warmup, 1)):
-            full_step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            full_step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        # ---- schedule 1: strictly serial (one graph, one stream) + the per-kernel roofline that belongs to it
+        plan.import_tiles(tiles["serial"])
+        conv_ms = conv_event_times(plan)
+        conv_flops = sum(st.flops for st in plan.conv_steps)
+        algo_bytes = conv_algorithmic_bytes(plan)
+        serial_server = InFlightDetector(model, x, depth=1, tiles=tiles["serial"])
+        serial = timer.measure(make_step(serial_server, 1), args.steps, args.warmup, args.repeats)
+        serial_server.drain()
+        # ---- schedule 2: --in-flight steps overlapped on as many streams (the default headline)
+        if n_fly > 1:
+            server = InFlightDetector(model, x, depth=n_fly, tiles=tiles["in_flight"])
+            fly = timer.measure(make_step(server, n_fly), args.steps, args.warmup, args.repeats)
+            server.drain()
+        else:
+            server, fly = serial_server, serial
         model.raise_if_error()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        check = None
+        if args.check and world > 1:
+            last = gathered[(server._next - 1) % n_fly].to(dev)
+            if rank == 0:
+                ref = []
+                for r in range(world):                                 # single-GPU forwards of every rank's images
+                    outs = model(images(r).to(dev))
+                    ref.append(hip_ops.detections(outs[0], outs[1], outs[2]).clone())
+                check = compare_records(last.cpu(), torch.cat(ref).cpu())
+            flag = torch.tensor([1 if (check is None or check["ok"]) else 0], device=dev if nccl else "cpu")
+            dist.broadcast(flag, src=0)
+            if int(flag.item()) == 0:
+                if rank == 0:
+                    print(json.dumps({"check": check}), file=sys.stderr, flush=True)
+                dist.barrier()
+                dist.destroy_process_group()
+                sys.exit(3)
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = n_gpus * B * args.steps / elapsed
+        head = fly
         conv_total_ms = sum(conv_ms)
         achieved = conv_flops / (conv_total_ms * 1e-3) / 1e12
-        traffic, traffic_note = (None, "skipped") if (n_gpus > 1 or args.no_pmc) else pmc_traffic(args, plan, len(conv_ms))
+        traffic, traffic_note = (None, "skipped") if (n_gpus > 1 or args.no_pmc) else pmc_traffic(args, tiles["serial"], len(conv_ms))
+        step_flops = conv_flops                                           # conv GEMM FLOPs of one step (B images)
         line = {
             "metric": "images/sec Faster R-CNN ResNet-50 @800x1333" if args.backbone == "resnet50"
                       else f"images/sec Faster R-CNN {args.backbone} @{args.height}x{args.width}",
-            "value": round(value, 3), "unit": "images/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "value": round(n_gpus * B / (head["ms_per_step"] * 1e-3), 3), "unit": "images/s", "n_gpus": n_gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(head["ms_per_step"], 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Full Faster R-CNN {args.backbone} inference forward, batch={B} per GPU, "
-                                   f"3x{args.height}x{args.width}, {args.num_classes}+1 classes, 3000->300 proposals",
+                                   f"3x{args.height}x{args.width}, {args.num_classes}+1 classes, 3000->300 proposals"
+                                   + (" (BASELINE configs[4]: data-parallel, 8 images per rank)" if world > 1 and B == 8 else ""),
                        "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}",
-                       "hip_graph": not args.no_graph, "autotuned_tiles": not args.no_autotune,
-                       "steps_in_flight": 1 if args.no_graph else max(1, args.in_flight),
+                       "hip_graph": True, "autotuned_tiles": not args.no_autotune, "steps_in_flight": n_fly,
                        "collective": None if n_gpus == 1 else f"all_gather_into_tensor [{n_gpus * B},300,6] f32 ({args.dist_backend})"},
+            "repeats": {"n": head["n"], "steps_each": head["steps"], "ms_per_step_median": round(head["ms_per_step"], 4),
+                        "ms_per_step_min": round(head["min"], 4), "ms_per_step_max": round(head["max"], 4)},
+            "serial": {"images_per_s": round(n_gpus * B / (serial["ms_per_step"] * 1e-3), 3),
+                       "ms_per_step": round(serial["ms_per_step"], 4), "ms_per_step_min": round(serial["min"], 4),
+                       "ms_per_step_max": round(serial["max"], 4), "repeats": serial["n"],
+                       "note": "one forward at a time on one stream (--in-flight 1 semantics) = latency of a step"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": None if traffic is None else round(traffic),
-                         "traffic_unit": "HBM bytes per conv launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 / launches, incl. the "
-                                         "K-slice reduce kernels" + ("" if traffic_note is None else f" [{traffic_note}]"),
-                         "algorithmic_bytes_per_launch": round(conv_algorithmic_bytes(plan) / len(conv_ms)),
+                         "traffic_unit": "HBM bytes per conv launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 / launches"
+                                         + ("" if traffic_note is None else f" [{traffic_note}]"),
+                         "algorithmic_bytes_per_launch": round(algo_bytes / len(conv_ms)),
+                         "traffic_over_algorithmic": None if traffic is None else round(traffic * len(conv_ms) / algo_bytes, 3),
                          "kernel": f"conv_igemm_kernel (f32 MFMA implicit GEMM), {len(conv_ms)} launches per forward",
-                         "flops_per_forward": conv_flops, "kernel_ms_per_forward": round(conv_total_ms, 4),
-                         "share_of_single_stream_forward": None if latency_ms is None else round(conv_total_ms / latency_ms, 4)},
-            "latency_ms_single_stream": None if latency_ms is None else round(latency_ms, 4),
+                         "schedule": "serial", "flops_per_forward": conv_flops,
+                         "kernel_ms_per_forward": round(conv_total_ms, 4),
+                         "serial_ms_per_step": round(serial["ms_per_step"], 4),
+                         "share_of_serial_step": round(conv_total_ms / serial["ms_per_step"], 4)},
+            "throughput_mode": {"steps_in_flight": n_fly, "conv_tflops_per_step_time": round(step_flops / (head["ms_per_step"] * 1e-3) / 1e12, 3),
+                                "frac_of_peak": round(step_flops / (head["ms_per_step"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                                "note": "conv FLOPs of a step / ms_per_step of the headline schedule: a whole-step bound "
+                                        "(non-GEMM kernels included in the time), not a per-kernel measurement"},
         }
+        if check is not None:
+            line["check"] = check
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, args.backbone, x_cpu, args.cpu_reps)
         print(json.dumps(line), flush=True)

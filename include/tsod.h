@@ -225,9 +225,11 @@ int tsod_roi_pool_avg_f32(const float *feat, int32_t B, int32_t Hf, int32_t Wf, 
 
 /* Final detection records (nets/frcnn_training.py:311-319): per RoI the arg-max class
  * over all n_class logits (first max wins), its raw logit, and loc2bbox(roi, loc of that class).
- *   cls_locs [K][4*n_class], scores [K][n_class], rois [K][4] -> det [K][6] = (x1,y1,x2,y2,score,class). */
-int tsod_detections_f32(const float *cls_locs, const float *scores, const float *rois, int32_t K,
-                        int32_t n_class, float *det, tsod_stream_t stream);
+ *   cls_locs [K] rows of 4*n_class floats (row pitch loc_pitch), scores [K] rows of n_class (pitch score_pitch) - both may
+ *   be column slices of one wider matrix, as the fused head GEMM writes them - rois [K][4]
+ *   -> det [K][6] = (x1,y1,x2,y2,score,class). */
+int tsod_detections_f32(const float *cls_locs, int32_t loc_pitch, const float *scores, int32_t score_pitch,
+                        const float *rois, int32_t K, int32_t n_class, float *det, tsod_stream_t stream);
 
 /* ---- inference-time filtering of the records (the step after the path) ------------------
  * The reference's demo keeps `nms(boxes_pred, labels_score_pred, iou_threshold=0.1)` over the records of an

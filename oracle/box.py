@@ -81,20 +81,26 @@ def enumerate_shifted_anchor(anchor_base: torch.Tensor, feat_stride: int, height
 
 # --------------------------------------------------------------------------- box math
 def loc2bbox(src_bbox: torch.Tensor, loc: torch.Tensor) -> torch.Tensor:
-    """utils/loc_bbox_iou.py:29-61 (empty-input guard :33-34)."""
+    """utils/loc_bbox_iou.py:29-61 (empty-input guard :33-34).  ``loc`` is [n,4] or, as the reference's strided
+    slices 0::4 .. 3::4 allow (:42-45, :55-58), [n,4k]: k offset sets per source box, output [n,4k]."""
     if src_bbox.shape[0] == 0:
         return torch.zeros((0, 4), dtype=loc.dtype)
-    x1, y1, x2, y2 = src_bbox.to(loc.dtype).unbind(1)
+    x1, y1, x2, y2 = (c.unsqueeze(-1) for c in src_bbox.to(loc.dtype).unbind(1))
     w = x2 - x1
     h = y2 - y1
     cx = x1 + 0.5 * w
     cy = y1 + 0.5 * h
-    dx, dy, dw, dh = loc.unbind(1)
+    dx, dy, dw, dh = loc[:, 0::4], loc[:, 1::4], loc[:, 2::4], loc[:, 3::4]
     ncx = dx * w + cx
     ncy = dy * h + cy
     nw = torch.exp(dw) * w
     nh = torch.exp(dh) * h
-    return torch.stack([ncx - 0.5 * nw, ncy - 0.5 * nh, ncx + 0.5 * nw, ncy + 0.5 * nh], dim=1)
+    out = torch.zeros_like(loc)
+    out[:, 0::4] = ncx - 0.5 * nw
+    out[:, 1::4] = ncy - 0.5 * nh
+    out[:, 2::4] = ncx + 0.5 * nw
+    out[:, 3::4] = ncy + 0.5 * nh
+    return out
 
 
 def bbox_iou(bbox_a: torch.Tensor, bbox_b: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:

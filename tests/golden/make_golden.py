@@ -87,6 +87,18 @@ def save(name, **arrs):
 
 
 @torch.inference_mode()
+def extras_round2():
+    """Fixtures added in round 2 (own seeds, own files: the round-1 files above are left byte-identical)."""
+    g = torch.Generator().manual_seed(20261004)
+    # loc2bbox with k box sets per row ([n,4k] locs, utils/loc_bbox_iou.py:42-57: the 0::4 / 1::4 / 2::4 / 3::4 strides)
+    src = torch.rand(40, 4, generator=g) * 500
+    src[:, 2:] = src[:, :2] + torch.rand(40, 2, generator=g) * 250 + 1
+    loc_k = torch.randn(40, 12, generator=g) * 0.4
+    save("boxmath_k.npz", src=src.numpy(), loc_k3=loc_k.numpy(), loc2bbox_k3=ref_box.loc2bbox(src, loc_k).numpy(),
+         empty=ref_box.loc2bbox(torch.zeros(0, 4), torch.zeros(0, 4)).numpy())
+
+
+@torch.inference_mode()
 def main():
     g = torch.Generator().manual_seed(20251003)
 
@@ -185,4 +197,6 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--extras-only" not in sys.argv:
+        main()
+    extras_round2()

@@ -79,7 +79,8 @@ def test_proposal_path_validation():
     assert L.tsod_bbox_iou_f32(P, 0, P, 4, 1e-8, P, None) == INVALID
     assert L.tsod_roi_pool_f32(P, 1, 8, 8, 6, 8, P, 4, 1.0, 7, 7, P, None) == ALIGNMENT               # C % 4
     assert L.tsod_roi_pool_avg_f32(P, 1, 8, 8, 8, 8, P, P, 4, 0., 64., 1.0, 7, 7, P, 8, None) == INVALID   # img_h = 0
-    assert L.tsod_detections_f32(P, P, P, 0, 81, P, None) == INVALID
+    assert L.tsod_detections_f32(P, 324, P, 81, P, 0, 81, P, None) == INVALID
+    assert L.tsod_detections_f32(P, 320, P, 81, P, 300, 81, P, None) == INVALID       # row pitch shorter than a row
 
 
 def test_filter_and_input_step_validation():

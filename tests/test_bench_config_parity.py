@@ -1,0 +1,135 @@
+"""GPU parity of exactly the configurations bench.py times (VERDICT r01 "what's weak" 1, 4):
+
+* the detector forward with the AUTOTUNED tile / K-slice table pinned (the committed tables under profiles/ and a
+  fresh ``Plan.autotune()``), not only the cost model's default choices that the other end-to-end tests run with;
+* the serving path bench.py's default line goes through (``InFlightDetector`` with those tiles: HIP graphs on
+  several streams);
+* BASELINE config 4: HarDNet-68 at batch 8, 3x800x1333.
+
+Bars as everywhere: boxes / scores <= 1e-3 absolute, arg-max classes bit-exact, RoIs position-wise equal where the
+scores are well separated (ResNet-50 seed 0: zero positional mismatches).
+"""
+import glob
+import json
+import os
+
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _img(shape, seed=1234):
+    return torch.rand(shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.fixture(scope="module")
+def r50():
+    from two_stage_object_detection_amd.testing import synthetic_detector
+    model, sd = synthetic_detector("resnet50", num_classes=80, seed=0)
+    x = _img((1, 3, 800, 1333))
+    with torch.inference_mode():
+        ref = oracle.detector_forward(sd, x, backbone="resnet50")
+    return model.to("cuda:0").eval(), sd, x, ref
+
+
+def _tile_tables():
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_autotuned_tiles_b1*.json")))
+
+
+@pytest.mark.parametrize("table", _tile_tables(), ids=os.path.basename)
+def test_detector_with_the_committed_autotuned_tile_tables(dev, r50, table):
+    """bench.py pins (tile, split_k) per layer from Plan.autotune(); the committed tables hold tiles 3..15 and
+    K-slice counts -1, 1, 3, 4, 6, 8, 12.  Same forward, those choices imported: same RoIs position for position."""
+    from two_stage_object_detection_amd.testing import compare_detector_outputs
+    model, sd, x, ref = r50
+    tiles = json.load(open(table))
+    xg = x.to(dev)
+    with torch.inference_mode():
+        model(xg)
+        plan = model.extractor._plan_for(xg)
+        before = plan.export_tiles()
+        plan.import_tiles(tiles)
+        assert plan.export_tiles() == [tuple(t) for t in tiles]
+        got = [o.cpu() for o in model(xg)]
+        model.raise_if_error()
+        plan.import_tiles(before)                                # leave the shared model as the other tests expect it
+    rep = compare_detector_outputs(got, ref)
+    print(os.path.basename(table), sorted({(t, s) for _, t, s in tiles}), rep)
+    assert rep["ok"], rep
+    assert rep["rows_positional_mismatch"] == 0 and rep["rows_unmatched"] == 0 and rep["class_mismatch"] == 0, rep
+
+
+def test_detector_after_plan_autotune_and_through_the_serving_path(dev, r50):
+    """What `python bench.py` does: Plan.autotune() on the box it runs on (candidates timed as two copies in flight),
+    then InFlightDetector(depth=4) replaying one HIP graph per slot on four streams.  Every slot's outputs are
+    checked against the oracle, and the eager forward with the tuned table as well."""
+    from two_stage_object_detection_amd.serving import InFlightDetector
+    from two_stage_object_detection_amd.testing import compare_detector_outputs
+    model, sd, x, ref = r50
+    xg = x.to(dev)
+    with torch.inference_mode():
+        model(xg)
+        plan = model.extractor._plan_for(xg)
+        before = plan.export_tiles()
+        res = plan.autotune(reps=2, concurrent=2)
+        tuned = plan.export_tiles()
+        assert len(res) == len(plan.conv_steps) == 53
+        assert all(t in range(1, 16) for _, t, _ in tuned)
+        got = [o.cpu() for o in model(xg)]
+        model.raise_if_error()
+        rep = compare_detector_outputs(got, ref)
+        print("autotuned eager", sorted({(t, s) for _, t, s in tuned}), rep)
+        assert rep["ok"] and rep["rows_positional_mismatch"] == 0 and rep["rows_unmatched"] == 0, rep
+        server = InFlightDetector(model, xg, depth=4, tiles=tuned)
+        tickets = [server.submit(xg) for _ in range(8)]
+        for t in tickets[4:]:
+            outs = [o.cpu() for o in server.result(t)]
+            r = compare_detector_outputs(outs[:4], ref)
+            assert r["ok"] and r["rows_positional_mismatch"] == 0 and r["rows_unmatched"] == 0, (t, r)
+            det_ref = oracle.detections_from_outputs(ref[0], ref[1], ref[2])
+            assert torch.equal(outs[4][..., 5], det_ref[..., 5])                     # class indices bit-exact
+            assert (outs[4][..., :5] - det_ref[..., :5]).abs().max().item() <= 1e-3
+        server.drain()
+        plan.import_tiles(before)
+
+
+def test_config4_hardnet68_batch8_full_size(dev):
+    """BASELINE config 4: HarDNet-68 (models/hardnet.py, depth_wise=True), batch 8, 3x800x1333.  Images 0 and 5 of the
+    batch are checked against the oracle; batched and single-image GPU forwards must agree to the parity bars (images
+    are independent units; the K-slice schedule - hence the f32 summation order - depends on the launch size)."""
+    from two_stage_object_detection_amd.testing import compare_detector_outputs, synthetic_detector
+    model, sd = synthetic_detector("hardnet68", num_classes=80, seed=0)
+    # random-init HarDNet with identity BN collapses to a spatially constant feature map (thousands of exactly tied RPN
+    # scores, for which the reference's argsort has no defined order): give BN the statistics a trained net would hold
+    oracle.calibrate_bn(sd, _img((2, 3, 256, 320), seed=99), oracle.hardnet_trunk, arch=68, prefix="extractor.")
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    x = _img((8, 3, 800, 1333), seed=21)
+    with torch.inference_mode():
+        got = [o.cpu() for o in model(x.to(dev))]
+        model.raise_if_error()
+        singles = {i: [o.cpu() for o in model(x[i:i + 1].to(dev))] for i in (0, 5)}
+        refs = {i: oracle.detector_forward(sd, x[i:i + 1], backbone="hardnet68") for i in (0, 5)}
+    assert got[2].shape == (8, 300, 4) and got[1].shape == (8, 300, 81)
+    report = {}
+    for i in (0, 5):
+        row = [got[0][i:i + 1], got[1][i:i + 1], got[2][i:i + 1], got[3][:1]]
+        r_single = compare_detector_outputs(row, singles[i])
+        r_oracle = compare_detector_outputs(row, refs[i])
+        report[i] = {"vs_single": {k: r_single[k] for k in ("rows_positional_mismatch", "rows_unmatched", "max_abs_roi",
+                                                              "max_abs_score", "class_mismatch")},
+                     "vs_oracle": {k: r_oracle[k] for k in ("rows_positional_mismatch", "rows_unmatched", "max_abs_roi",
+                                                              "max_abs_score", "class_mismatch")}}
+        assert r_single["ok"] and r_oracle["ok"], (i, r_single, r_oracle)
+        # every RoI of the batched run exists in the oracle's list (isolated sort swaps move positions, not members)
+        assert r_oracle["rows_unmatched"] == 0 and r_oracle["class_mismatch"] == 0, (i, r_oracle)
+        assert r_oracle["rows_positional_mismatch"] <= 12 and r_single["rows_unmatched"] == 0, (i, r_oracle, r_single)
+    print("config4", json.dumps(report))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        json.dump(report, open(os.path.join(out_dir, "config4_parity.json"), "w"))

@@ -60,3 +60,38 @@ def test_shard_range():
 def test_single_process_is_identity():
     d = torch.randn(2, 300, 6)
     assert all_gather_detections(d) is d
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` (the shape of the driver's command, no torchrun, no WORLD_SIZE): bench.py must start the
+    two ranks itself.  --rehearse-cpu swaps the forwards for fabricated records so that the launcher, the rendezvous
+    on 127.0.0.1, the timed-region protocol (barrier / max over ranks / repeats), the all-gather into the pre-allocated
+    buffer and the --check comparison all run here on CPU with gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-cpu", "--check",
+                        "--steps", "3", "--warmup", "1", "--repeats", "2", "--batch", "3"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                   # rank 0 prints ONE line
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 6 and line["config"]["parallelism"] == "dp2"
+    assert line["rehearsal"] is True and line["value"] is None          # never mistaken for a measurement
+    assert line["check"] == {"ok": True, "classes_equal": True, "max_abs_box_score": 0.0, "images": 6}
+    assert line["steps"] == 3 and line["scaling"] == "weak"
+
+
+def test_bench_refuses_more_nccl_ranks_than_gpus(monkeypatch):
+    """Without a GPU per rank RCCL cannot run: bench.py must say so and exit non-zero instead of printing n_gpus: 1."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "needs a GPU" in (r.stdout + r.stderr) or "visible GPU" in (r.stdout + r.stderr)

@@ -189,10 +189,13 @@ def test_detector_end_to_end(dev, synth, backbone, shape, ncls):
         model.raise_if_error()
     rep = compare_detector_outputs(got, ref)
     print(backbone, shape, rep)
-    # isolated discrete flips are tolerated (reported), everything that is matched must meet the bar
-    assert rep["ok"], rep
+    # everything that is matched must meet the bar, and every RoI must be matched: the two f32 pipelines may order two
+    # near-tied scores differently (a swap moves positions: counted in rows_positional_mismatch, HarDNet seeds show 0-8
+    # of 300), but the RoI SET is the same
+    assert rep["ok"] and rep["rows_unmatched"] == 0 and rep["class_mismatch"] == 0, rep
+    assert rep["rows_positional_mismatch"] <= 8, rep
     if backbone == "resnet50":
-        assert rep["rows_positional_mismatch"] == 0 and rep["rows_unmatched"] == 0, rep   # well-separated scores: exact
+        assert rep["rows_positional_mismatch"] == 0, rep                                    # well-separated scores: exact
 
 
 def test_config3_batch16_full_size(dev, synth):
@@ -434,3 +437,86 @@ def test_forward_needs_no_grad_mode_context(dev, synth):
     for a, b, c, d in zip(ref, plain, ng, staged):
         assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d) and not b.requires_grad
     model.raise_if_error()
+
+
+def test_forward_then_load_state_dict_then_forward_uses_the_new_weights(dev):
+    """plans / packed weights built by a first forward must not survive a checkpoint load through the
+    detector (load_state_dict and load_trainer_checkpoint), and a graph captured before the load refuses to replay."""
+    from two_stage_object_detection_amd._ffi import TsodError
+    from two_stage_object_detection_amd.testing import compare_detector_outputs, synthetic_detector
+    model, sd_a = synthetic_detector("resnet50", num_classes=20, seed=0)
+    _, sd_b = synthetic_detector("resnet50", num_classes=20, seed=7)
+    model = model.to(dev).eval()
+    x = _img((1, 3, 256, 320), seed=3)
+    with torch.inference_mode():
+        ref_a = oracle.detector_forward(sd_a, x, backbone="resnet50")
+        ref_b = oracle.detector_forward(sd_b, x, backbone="resnet50")
+        got_a = [o.cpu() for o in model(x.to(dev))]
+        run, _, _ = model.make_graphed(x.to(dev))
+        run()
+        model.load_state_dict(sd_b)                                          # through the PARENT module
+        got_b = [o.cpu() for o in model(x.to(dev))]
+        with pytest.raises(TsodError, match="weights changed"):
+            run()
+        trainer_sd = {("feat_extra." + k[len("extractor."):] if k.startswith("extractor.") else k): v for k, v in sd_a.items()}
+        model.load_trainer_checkpoint({"model_state_dict": trainer_sd})      # train/train.py:120-128 format
+        got_a2 = [o.cpu() for o in model(x.to(dev))]
+        model.raise_if_error()
+    assert not torch.equal(ref_a[2], ref_b[2])
+    for got, ref in ((got_a, ref_a), (got_b, ref_b), (got_a2, ref_a)):
+        rep = compare_detector_outputs(got, ref)
+        assert rep["ok"] and rep["rows_unmatched"] == 0, rep
+    for a, b in zip(got_a, got_a2):
+        assert torch.equal(a, b)
+
+
+def test_scratch_is_owned_by_detector_and_slot_not_by_the_stream_handle(dev, synth):
+    """torch hands out stream handles from a pool of 32 per device, so 'one scratch buffer per stream
+    handle' lets two graphs share split-K slabs / NMS masks.  Two detectors with three slots each, captured after more
+    than 32 streams were created, replayed concurrently on fresh streams: every slot reproduces its serial result."""
+    from two_stage_object_detection_amd import hip_ops
+    from two_stage_object_detection_amd.testing import synthetic_detector
+    model_a, _ = synth("resnet50")
+    model_b, _ = synthetic_detector("resnet50", num_classes=20, seed=3)
+    model_b = model_b.to(dev).eval()
+    burn = [torch.cuda.Stream(dev) for _ in range(40)]                       # wraps torch's stream pool
+    xs = [_img((1, 3, 224, 288), seed=70 + i).to(dev) for i in range(6)]
+    with torch.inference_mode():
+        jobs = []
+        for i, x in enumerate(xs):
+            m = model_a if i % 2 == 0 else model_b
+            serial = [o.clone() for o in m(x)]
+            jobs.append((m.make_graphed(x, slot=i // 2), serial))
+        owners = {k[2] for k in hip_ops.ARENA._buf if k[1] == "owner"}
+        assert {(model_a._uid, s) for s in range(3)} | {(model_b._uid, s) for s in range(3)} <= owners
+        streams = [torch.cuda.Stream(dev) for _ in xs]
+        torch.cuda.synchronize()
+        for it in range(20):
+            for (runner, _), st in zip(jobs, streams):
+                with torch.cuda.stream(st):
+                    runner[0]()
+        torch.cuda.synchronize()
+        for i, (runner, serial) in enumerate(jobs):
+            for a, b in zip(serial[:3], runner[2][:3]):
+                assert torch.equal(a, b), f"job {i}"
+    del burn
+
+
+def test_retuning_a_plan_keeps_earlier_graphs_valid(dev, synth):
+    """Plan.finalize() (reached from autotune / import_tiles) may need a larger K-slice workspace: the old buffer stays
+    alive for graphs captured earlier, which keep replaying the schedule they were captured with."""
+    model, _ = synth("resnet50")
+    x = _img((1, 3, 256, 320), seed=8).to(dev)
+    with torch.inference_mode():
+        ref = [o.clone() for o in model(x)]
+        run, _, outs = model.make_graphed(x, slot=5)
+        plan = model.extractor._plan_for(x, 5)
+        ws_before = plan.workspace
+        plan.import_tiles([(n, 3, 16) for n, _, _ in plan.export_tiles()])     # every layer K-sliced 16x: bigger workspace
+        assert plan.workspace is not ws_before and any(w is ws_before for w in plan._retired)
+        torch.empty(64 << 20, device=dev).fill_(1.0)                           # would land in a freed workspace
+        run()
+        torch.cuda.synchronize()
+        for a, b in zip(ref[:3], outs[:3]):
+            assert torch.equal(a, b)
+        model.extractor.drop_plan(slot=5)

@@ -58,20 +58,33 @@ def _conv_ref(x, w, stride, pad):
     return F.conv2d(x.double(), w.double(), None, stride, pad).float()
 
 
+_CONV_REF_CACHE = {}
+
+
+def _conv_case(case, dev, ops):
+    """(reference f64 conv on the CPU, NHWC input on the GPU, packed weight on the GPU), cached per case: the same
+    operands go through every tile variant and K-slice schedule."""
+    if case not in _CONV_REF_CACHE:
+        N, H, W, Cin, Cout, k, stride, pad = case
+        g = torch.Generator().manual_seed(hash(case) % 1000)
+        x = torch.randn(N, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+        _CONV_REF_CACHE[case] = (_conv_ref(x, w, stride, pad), ops.nchw_to_nhwc(x.to(dev)), ops.pack_conv_weight(w.to(dev)))
+    return _CONV_REF_CACHE[case]
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("tile", [0] + list(__import__("two_stage_object_detection_amd._ffi", fromlist=["TILE_IDS"]).TILE_IDS))
 def test_conv_matches_cpu(ops, dev, case, tile):
+    """Every tile variant of include/tsod.h (TILE_IDS: 1..15, 0 = the cost model's pick) under every K-slice schedule the
+    autotuner may pin (1 = whole tiles, -1 = hybrid, S = S slices: bench.py's tables hold 3, 4, 6, 8 and 12)."""
     N, H, W, Cin, Cout, k, stride, pad = case
-    g = torch.Generator().manual_seed(hash(case) % 1000)
-    x = torch.randn(N, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
-    ref = _conv_ref(x, w, stride, pad)
-    xn = ops.nchw_to_nhwc(x.to(dev))
-    wp = ops.pack_conv_weight(w.to(dev))
-    for split in ([0, 1, 3, -1] if tile in (0, 3) else [0, -1]):
+    ref, xn, wp = _conv_case(case, dev, ops)
+    ksteps = (Cin * k * k + 31) // 32
+    tol = 3e-6 * math.sqrt(Cin * k * k) + 1e-5
+    for split in [0, 1, -1] + [s for s in (2, 3, 4, 6, 8, 12, 16) if ksteps // s >= 2]:
         y = ops.conv2d_nhwc(xn, wp, stride=stride, pad=pad, tile=tile, split_k=split)
         got = ops.nhwc_to_nchw(y).cpu()
-        tol = 3e-6 * math.sqrt(Cin * k * k) + 1e-5
         assert (got - ref).abs().max().item() <= tol, (case, tile, split)
 
 
@@ -347,3 +360,46 @@ def test_detections(ops, dev):
     assert torch.equal(got[..., 4], ref[..., 4])
     assert (got[..., :4] - ref[..., :4]).abs().max().item() < 1e-3
     assert got[0, 0, 5].item() == 5.0
+
+
+# ----------------------------------------------------------------------------- stand-alone utils surface vs the reference's vectors
+def test_utils_loc2bbox_matches_the_references_vectors(dev, golden_dir):
+    """utils.loc_bbox_iou.loc2bbox (reference :29-61) through tsod_loc2bbox_f32, both call shapes: [n,4] and the
+    [n,4k] form of the strided slices (:42-45), against outputs of the reference's own function (make_golden.py)."""
+    import os
+    from two_stage_object_detection_amd.utils.loc_bbox_iou import loc2bbox, bbox_iou
+    z = np.load(os.path.join(golden_dir, "boxmath.npz"))
+    got = loc2bbox(torch.from_numpy(z["src"]).to(dev), torch.from_numpy(z["loc"]).to(dev)).cpu().numpy()
+    assert got.shape == z["loc2bbox"].shape
+    assert np.abs(got - z["loc2bbox"]).max() <= 1e-3                      # the north star's box bar; in practice ~1 ulp (exp)
+    assert np.abs(got - z["loc2bbox"]).max() <= 2e-4
+    zk = np.load(os.path.join(golden_dir, "boxmath_k.npz"))
+    gk = loc2bbox(torch.from_numpy(zk["src"]).to(dev), torch.from_numpy(zk["loc_k3"]).to(dev)).cpu().numpy()
+    assert gk.shape == (40, 12)
+    assert np.abs(gk - zk["loc2bbox_k3"]).max() <= 2e-4
+    empty = loc2bbox(torch.zeros(0, 4, device=dev), torch.zeros(0, 4, device=dev))
+    assert tuple(empty.shape) == (0, 4)
+    iou = bbox_iou(torch.from_numpy(z["iou_a"]).to(dev), torch.from_numpy(z["iou_b"]).to(dev)).cpu().numpy()
+    assert np.abs(iou - z["iou"]).max() <= 1e-7
+    d1 = torch.tensor([[100., 100, 200, 200]], device=dev)
+    d2 = torch.tensor([[150., 150, 250, 250]], device=dev)
+    assert np.allclose(bbox_iou(d1, d2).cpu().numpy(), z["known_iou"], atol=1e-7)
+
+
+def test_utils_anchor_functions_match_the_references_vectors(dev, golden_dir):
+    """utils.basic_anchors.generate_basic_anchor / enumerate_shifted_anchor (reference :11-23, :27-57) through
+    tsod_enumerate_anchors_f32 against the reference's own outputs: exact f32 adds -> bit-exact."""
+    import os
+    from two_stage_object_detection_amd.utils.basic_anchors import enumerate_shifted_anchor, generate_basic_anchor
+    z = np.load(os.path.join(golden_dir, "anchors.npz"))
+    base = generate_basic_anchor()
+    assert np.array_equal(base.cpu().numpy(), z["base"])
+    alt = generate_basic_anchor(base_size=16, ratios=[0.5, 1, 2, 3], anchor_scales=[4, 8])
+    assert np.array_equal(alt.cpu().numpy(), z["base_alt"])
+    base = base.to(dev)
+    assert np.array_equal(enumerate_shifted_anchor(base, 16, 3, 5).cpu().numpy(), z["shifted_s16_h3_w5"])
+    assert np.array_equal(enumerate_shifted_anchor(base, 32, 2, 3).cpu().numpy(), z["shifted_s32_h2_w3"])
+    full = enumerate_shifted_anchor(base, 16, 50, 84).cpu()
+    assert full.shape == (37800, 4)
+    assert np.array_equal(full[[0, 9, 755, 756, 37799]].numpy(), z["shifted_s16_h50_w84_rows"])
+    assert torch.equal(full, oracle.enumerate_shifted_anchor(base.cpu(), 16, 50, 84))

@@ -88,3 +88,84 @@ def test_state_dicts_equal_the_references_under_the_same_seed():
         torch.manual_seed(0); b = ref().state_dict()
         assert list(a.keys()) == list(b.keys())
         assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_install_dropin_resolves_the_references_import_paths():
+    """code written against the reference (``from nets.frcnn import FasterRCNN`` ...) imports unchanged after
+    ``install_dropin()``.  Run in a child interpreter so that the aliases do not leak into this test session."""
+    import subprocess
+    import sys
+    code = """
+import two_stage_object_detection_amd as pkg
+pkg.install_dropin()
+from nets.frcnn import FasterRCNN
+from nets.rpn import RegionProposalNetwork, ProposalCreator
+from nets.classify import HarNetRoIHead
+from models.resnet import resnet34, resnet50, resnet101, resnext50_32x4d, ResNet, Bottleneck, BasicBlock
+from models.hardnet import HarDNetFeatureExtraction, HarNetClassifier, HarDBlock, ConvLayer, DWConvLayer, CombConvLayer
+from utils.basic_anchors import generate_basic_anchor, enumerate_shifted_anchor
+from utils.loc_bbox_iou import bbox_iou, loc2bbox
+from dataset.transform import eval_transform
+import nets.frcnn, two_stage_object_detection_amd.nets.frcnn as mine
+assert nets.frcnn is mine and FasterRCNN is mine.FasterRCNN
+pkg.install_dropin()                      # idempotent
+m = FasterRCNN(num_classes=3)
+assert type(m.rpn) is RegionProposalNetwork and type(m.head) is HarNetRoIHead
+import sys, types
+sys.modules['utils'] = types.ModuleType('utils')        # a foreign top-level package of the same name
+try:
+    pkg.install_dropin()
+except ImportError:
+    pass
+else:
+    raise SystemExit('install_dropin() silently replaced a foreign package')
+pkg.install_dropin(force=True)
+print('dropin ok')
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "dropin ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_loading_weights_through_the_detector_invalidates_every_packed_copy(tmp_path):
+    """nn.Module.load_state_dict on a parent recurses through _load_from_state_dict and never calls a child's
+    load_state_dict: the backbone / RPN / head register a post-hook instead, which fires on every path."""
+    torch.manual_seed(5)
+    for backbone in ("resnet50", "hardnet39"):
+        m = FasterRCNN(num_classes=4, backbone=backbone).eval()
+        for sub in (m.extractor, m.rpn, m.head):
+            sub._packed_cache[("sentinel", "cpu")] = object()
+            sub._plans[("sentinel",)] = object()
+        v0 = m.weights_version()
+        m.load_state_dict(m.state_dict())
+        assert all(not sub._packed_cache and not sub._plans for sub in (m.extractor, m.rpn, m.head))
+        v1 = m.weights_version()
+        assert all(b > a for a, b in zip(v0, v1))
+        trainer_sd = {("feat_extra." + k[len("extractor."):] if k.startswith("extractor.") else k): v
+                      for k, v in m.state_dict().items()}
+        m.extractor._packed_cache[("sentinel", "cpu")] = object()
+        m.load_trainer_checkpoint({"model_state_dict": trainer_sd})
+        assert not m.extractor._packed_cache and all(b > a for a, b in zip(v1, m.weights_version()))
+        v2 = m.weights_version()
+        m.extractor.load_state_dict(m.extractor.state_dict())           # directly on the child as well
+        assert m.weights_version()[0] > v2[0] and m.weights_version()[1:] == v2[1:]
+        m.invalidate_packed()
+        assert all(b > a for a, b in zip(v2, m.weights_version()))
+    import copy
+    m2 = copy.deepcopy(m)                                                # plans / packed weights are not copied
+    assert not m2.extractor._plans and m2.state_dict().keys() == m.state_dict().keys()
+
+
+def test_plan_cache_is_lru_bounded():
+    from collections import OrderedDict
+    m = resnet50(include_top=False).eval()
+    m.max_plans = 3
+    built = []
+    for i in range(5):
+        m._cached_plan(((1, 3, 32 * (i + 1), 64), "cuda:0", 0), lambda i=i: built.append(i) or f"plan{i}")
+    assert list(m._plans.values()) == ["plan2", "plan3", "plan4"]
+    m._cached_plan(((1, 3, 96, 64), "cuda:0", 0), lambda: built.append("again") or "never")     # hit: moves to the end
+    assert built == [0, 1, 2, 3, 4] and list(m._plans.values())[-1] == "plan2"
+    m.drop_plan(shape=(1, 3, 128, 64))
+    assert list(m._plans.values()) == ["plan4", "plan2"]
+    assert isinstance(m._plans, OrderedDict)

@@ -122,12 +122,12 @@ proposal_decode_kernel(const float *__restrict__ anchor, const float *__restrict
 // One wave per RoI: arg-max over n_class logits (first maximum wins), then loc2bbox with the
 // 4 offsets of that class (nets/frcnn_training.py:311-319).
 __global__ void __launch_bounds__(256)
-detections_kernel(const float *__restrict__ cls_locs, const float *__restrict__ scores,
+detections_kernel(const float *__restrict__ cls_locs, int loc_pitch, const float *__restrict__ scores, int score_pitch,
                   const float *__restrict__ rois, int K, int n_class, float *__restrict__ det) {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (k >= K) return;
-    const float *s = scores + (long)k * n_class;
+    const float *s = scores + (long)k * score_pitch;
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int c = lane; c < n_class; c += 64) {
@@ -140,7 +140,7 @@ detections_kernel(const float *__restrict__ cls_locs, const float *__restrict__ 
         if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
     }
     if (lane == 0) {
-        const float *l = cls_locs + ((long)k * n_class + bi) * 4;
+        const float *l = cls_locs + (long)k * loc_pitch + bi * 4;
         const float *r = rois + (long)k * 4;
         Box o = decode_box(r[0], r[1], r[2], r[3], l[0], l[1], l[2], l[3]);
         float *d = det + (long)k * 6;
@@ -194,13 +194,13 @@ extern "C" int tsod_rpn_decode_f32(const float *locs, int32_t loc_pitch, const f
     return tsod_launch_status();
 }
 
-extern "C" int tsod_detections_f32(const float *cls_locs, const float *scores, const float *rois, int32_t K,
-                                   int32_t n_class, float *det, tsod_stream_t stream) {
+extern "C" int tsod_detections_f32(const float *cls_locs, int32_t loc_pitch, const float *scores, int32_t score_pitch,
+                                   const float *rois, int32_t K, int32_t n_class, float *det, tsod_stream_t stream) {
     TSOD_REQUIRE(cls_locs && scores && rois && det, TSOD_ERR_INVALID_ARG);
-    TSOD_REQUIRE(K > 0 && n_class > 0, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(K > 0 && n_class > 0 && loc_pitch >= 4 * n_class && score_pitch >= n_class, TSOD_ERR_INVALID_ARG);
     const int waves_per_block = 4;
     hipLaunchKernelGGL(detections_kernel, dim3((K + waves_per_block - 1) / waves_per_block), dim3(64 * waves_per_block),
-                       0, tsod_stream(stream), cls_locs, scores, rois, K, n_class, det);
+                       0, tsod_stream(stream), cls_locs, loc_pitch, scores, score_pitch, rois, K, n_class, det);
     return tsod_launch_status();
 }
 

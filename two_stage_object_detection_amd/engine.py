@@ -10,6 +10,7 @@ Data layout in HBM: every activation is NHWC f32, channel pitch a multiple of 4,
 """
 from __future__ import annotations
 
+from collections import OrderedDict
 from ctypes import byref, c_int32
 from typing import Callable, Sequence
 
@@ -102,9 +103,11 @@ class ConvStep:
 
 
 class Plan:
-    def __init__(self, device):
+    def __init__(self, device, packed: dict | None = None):
         self.device = torch.device(device)
         self.pool = BufferPool(self.device)
+        self._packed = packed if packed is not None else {}   # the owner's packed-weight cache (shared by all its plans)
+        self._retired: list = []             # outgrown workspaces: graphs captured earlier still hold their pointers
         self.steps: list[list] = []          # [cfunc, [args...]]
         self.conv_steps: list[ConvStep] = []
         self.keep: list = []                 # keeps descriptors / tensors alive
@@ -114,6 +117,15 @@ class Plan:
         self.flops = 0
 
     # -- building ---------------------------------------------------------------------------
+    def packed(self, key, make: Callable):
+        """The packed form of a layer's weights, built once per (layer, device) and shared by every plan (input
+        geometry, in-flight slot) of the owning module."""
+        key = (key, self.device)
+        obj = self._packed.get(key)
+        if obj is None:
+            obj = self._packed[key] = make()
+        return obj
+
     def call(self, fn, *args, keep=()):
         self.steps.append([fn, list(args)])
         self.keep.extend(keep)
@@ -161,9 +173,10 @@ class Plan:
             st.ws_bytes = lib().tsod_conv2d_workspace_bytes(byref(st.desc))
             need = max(need, st.ws_bytes)
         if self.workspace is None or self.workspace.numel() < need:
-            # zero-initialised: the head of the workspace holds the K-slice arrival tickets, which every
-            # launch expects to find zero and leaves zero
-            self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
+            if self.workspace is not None:
+                # a HIP graph captured from this plan earlier has the old pointer baked in: the buffer must outlive it
+                self._retired.append(self.workspace)
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         for st in self.conv_steps:
             st.args[7] = ptr(self.workspace)
             st.args[8] = self.workspace.numel()
@@ -219,7 +232,10 @@ class Plan:
             cands = []
             for tile in _ffi.TILE_IDS:
                 for split in (splits or (1, -1, 2, 3, 4, 6, 8, 12, 16, 24, 32)):
-                    if split > 1 and (ksteps // split < 2 or split * (M + 128) * (d.Cout + 128) * 4 > big.numel()):
+                    if split > 1 and ksteps // split < 2:
+                        continue
+                    d.tile, d.split_k = tile, split
+                    if lib().tsod_conv2d_workspace_bytes(byref(d)) > big.numel():   # exact need of THIS (tile, split)
                         continue
                     cands.append((tile, split))
             best = None
@@ -228,12 +244,14 @@ class Plan:
             for tile, split in cands:
                 d.tile, d.split_k = tile, split
                 s = stream_ptr()
-                lib().tsod_conv2d_f32(*args, s)          # warm
+                rc = lib().tsod_conv2d_f32(*args, s)          # warm
+                if rc != 0:
+                    continue                                  # a candidate the library refuses is skipped, not fatal
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 if concurrent == 1:
                     e0.record()
                     for _ in range(reps):
-                        rc = lib().tsod_conv2d_f32(*args, s)
+                        rc |= lib().tsod_conv2d_f32(*args, s)
                     e1.record()
                 else:
                     cur = torch.cuda.current_stream(self.device)
@@ -243,7 +261,7 @@ class Plan:
                     for st2 in side:
                         st2.wait_stream(cur)
                     for _ in range(reps):
-                        rc = lib().tsod_conv2d_f32(*args, s)
+                        rc |= lib().tsod_conv2d_f32(*args, s)
                         for ci, st2 in enumerate(side):
                             a2 = list(args)
                             a2[7] = ptr(bigs[ci + 1])
@@ -252,10 +270,13 @@ class Plan:
                         cur.wait_stream(st2)
                     e1.record()
                 e1.synchronize()
-                check(rc, "autotune conv")
+                if rc != 0:
+                    continue
                 t = e0.elapsed_time(e1) / (reps * concurrent)
                 if best is None or t < best[0]:
                     best = (t, tile, split)
+            if best is None:
+                raise TsodError(f"autotune: no runnable (tile, split) candidate for {st.name}")
             d.tile, d.split_k = best[1], best[2]
             results.append((st.name, best[0], best[1], best[2], st.flops))
             if verbose:
@@ -286,6 +307,97 @@ class Plan:
             lib().tsod_conv2d_resolve(byref(st.desc), byref(t), byref(s))
             out.append((st.name, t.value, s.value))
         return out
+
+
+def _invalidate_after_load(module, incompatible_keys):
+    module.invalidate_packed()
+
+
+class PlanOwner:
+    """Mixin of the modules that own launch plans and packed weights (the backbones, the RPN, the RoI head).
+
+    * ``_plans``: LRU-bounded cache of plans keyed by (input shape, device, slot) - a stream of differently sized
+      inputs cannot grow HBM without bound (``max_plans``; a plan evicted here stays alive for as long as a HIP graph's
+      ``run`` closure references it).
+    * ``_packed_cache``: folded / packed weights per (layer, device), shared by all plans and in-flight slots.
+    * Both are dropped whenever the weights may have changed: ``.to()`` / ``.cuda()`` (``_apply``) and EVERY
+      ``load_state_dict`` that reaches this module, also through a parent (``nn.Module.load_state_dict`` recurses via
+      ``_load_from_state_dict`` and never calls a child's ``load_state_dict``; the post-hook registered here does fire).
+      In-place edits of parameters (``p.data.mul_()``, an optimiser step) are invisible: call ``invalidate_packed()``.
+    * ``weights_version`` counts invalidations: a graph captured by ``FasterRCNN.make_graphed`` refuses to replay once it
+      is stale (it would run the old folded weights)."""
+    max_plans = 8
+
+    def _init_plan_owner(self):
+        self.__dict__["_plans"] = OrderedDict()
+        self.__dict__["_packed_cache"] = {}
+        self.__dict__["weights_version"] = 0
+        self.register_load_state_dict_post_hook(_invalidate_after_load)
+
+    def invalidate_packed(self):
+        """Drop compiled plans and packed weights (call after changing weights in place)."""
+        self.__dict__["_plans"] = OrderedDict()
+        self.__dict__["_packed_cache"] = {}
+        self.__dict__["weights_version"] = self.__dict__.get("weights_version", 0) + 1
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_packed()
+        return super()._apply(fn, *a, **k)
+
+    def __getstate__(self):                       # copy.deepcopy / pickling: plans hold ctypes objects and raw pointers
+        st = self.__dict__.copy()
+        st["_plans"], st["_packed_cache"] = OrderedDict(), {}
+        return st
+
+    def _cached_plan(self, key, build: Callable):
+        plans = self._plans
+        plan = plans.get(key)
+        if plan is None:
+            plan = plans[key] = build()
+            while len(plans) > max(1, int(self.max_plans)):
+                plans.popitem(last=False)
+        else:
+            plans.move_to_end(key)
+        return plan
+
+    # -- the backbones' plan lookup (build_plan(N, H, W, device) is theirs) ---------------------
+    def _plan_for_shape(self, shape, device, slot: int = 0) -> "Plan":
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise TsodError("a CUDA/ROCm device is required")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        shape = tuple(int(v) for v in shape)
+
+        def build():
+            if self.training:
+                raise TsodError("the HIP path implements the inference forward only: call .eval() first")
+            return self.build_plan(shape[0], shape[2], shape[3], device)
+        # slot: independent buffer sets for forwards in flight concurrently (the packed weights are shared)
+        return self._cached_plan((shape, device, slot), build)
+
+    def _plan_for(self, x, slot: int = 0) -> "Plan":
+        _ffi.require_cuda(x, type(self).__name__ + ".forward")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise TsodError(f"expected [N,3,H,W], got {tuple(x.shape)}")
+        return self._plan_for_shape(x.shape, x.device, slot)
+
+    def forward_nhwc(self, x, slot: int = 0) -> torch.Tensor:
+        """[N,3,H,W] (or NHWC4Images) -> NHWC feature map (plan-owned buffer, valid until the next forward)."""
+        plan = self._plan_for(x, slot)
+        stage_input(plan, x)
+        plan.run()
+        return plan.output_nhwc
+
+    def input_buffer(self, N, H, W, device, slot: int = 0):
+        """The plan's own input buffer for [N,3,H,W] images as ``NHWC4Images``: an input pipeline that writes there
+        (dataset.transform.EvalTransform.batch(..., out=...)) hands its result to the first conv without any copy."""
+        return _ffi.NHWC4Images(self._plan_for_shape((N, 3, H, W), device, slot).input_nhwc)
+
+    def drop_plan(self, shape=None, slot=None):
+        """Forget the plans of an input shape and / or slot (their buffers are freed once no graph references them)."""
+        for key in [k for k in self._plans if (shape is None or k[0] == tuple(shape)) and (slot is None or k[2] == slot)]:
+            del self._plans[key]
 
 
 def stage_input(plan: "Plan", x) -> None:

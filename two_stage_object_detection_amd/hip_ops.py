@@ -5,7 +5,9 @@ only) and launches the HIP kernel on torch's current stream.  No fallback of any
 """
 from __future__ import annotations
 
+import contextlib
 import math
+import threading
 from ctypes import byref, c_int32
 
 import torch
@@ -16,20 +18,51 @@ from ._ffi import ACT_NONE, check, lib, make_conv_desc, ptr, require_cuda, strea
 
 # ----------------------------------------------------------------------------- workspace arena
 class _Arena:
-    """One growable scratch tensor per (device, stream) (split-K slabs, NMS masks)."""
+    """Growable scratch tensors (split-K slabs of the RPN / head GEMMs, NMS masks).
+
+    Keyed by an explicit OWNER when one is in scope (``with ARENA.scope(owner)``: the detector enters one per
+    (model, in-flight slot), so two slots or two detectors never share scratch whatever streams their graphs are
+    replayed on), else by (device, current stream): stand-alone eager calls on one stream are ordered by that stream,
+    and torch handing the same handle out twice means it IS the same HIP stream.
+    A buffer that has been handed out is never freed or replaced under a HIP graph that may have its pointer baked in:
+    outgrown buffers are retired, not released (``release(owner)`` drops an owner's buffers explicitly)."""
 
     def __init__(self):
         self._buf = {}
+        self._retired = {}
+        self._tls = threading.local()
+
+    @contextlib.contextmanager
+    def scope(self, owner):
+        prev = getattr(self._tls, "owner", None)
+        self._tls.owner = owner
+        try:
+            yield
+        finally:
+            self._tls.owner = prev
+
+    def _key(self, device):
+        owner = getattr(self._tls, "owner", None)
+        if owner is not None:
+            return (device, "owner", owner)
+        return (device, "stream", torch.cuda.current_stream(device).cuda_stream)
 
     def get(self, device, nbytes: int) -> torch.Tensor:
         nbytes = max(int(nbytes), 256)
-        # one scratch buffer per (device, stream): forwards in flight on different streams must not share slabs
-        device = (device, torch.cuda.current_stream(device).cuda_stream)
-        cur = self._buf.get(device)
+        key = self._key(device)
+        cur = self._buf.get(key)
         if cur is None or cur.numel() < nbytes:
-            cur = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device[0])
-            self._buf[device] = cur
+            if cur is not None:
+                self._retired.setdefault(key, []).append(cur)
+            cur = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+            self._buf[key] = cur
         return cur
+
+    def release(self, owner) -> None:
+        """Drop every buffer of ``owner`` (only once no graph captured under that owner will be replayed again)."""
+        for key in [k for k in self._buf if k[1] == "owner" and k[2] == owner]:
+            self._buf.pop(key, None)
+            self._retired.pop(key, None)
 
 
 ARENA = _Arena()
@@ -156,17 +189,18 @@ def gconv1x1_pair_nhwc(x: torch.Tensor, w_g2: torch.Tensor, bias=None) -> torch.
 # ----------------------------------------------------------------------------- proposal path
 def rpn_decode(locs: torch.Tensor, scores: torch.Tensor, anchor_base: torch.Tensor, B, Hf, Wf, feat_stride,
                clamp_x, clamp_y, min_size, want_anchors=False):
-    """locs [B*Hf*Wf, 4A] , scores [B*Hf*Wf, 2A] (row pitch = last dim) ->
+    """locs [B*Hf*Wf, 4A] , scores [B*Hf*Wf, 2A] (rows may be slices of a wider buffer: row pitch = stride(0)) ->
     boxes [B,Hf*Wf*A,4], fg [B,n], keys [B,n] (+ anchors [n,4])."""
     require_cuda(locs, "rpn_decode")
     A = anchor_base.shape[0]
+    assert locs.stride(1) == 1 and scores.stride(1) == 1 and locs.shape[1] == 4 * A and scores.shape[1] == 2 * A
     n = Hf * Wf * A
     dev = locs.device
     boxes = torch.empty((B, n, 4), dtype=torch.float32, device=dev)
     fg = torch.empty((B, n), dtype=torch.float32, device=dev)
     keys = torch.empty((B, n), dtype=torch.float32, device=dev)
     anchors = torch.empty((n, 4), dtype=torch.float32, device=dev) if want_anchors else None
-    check(lib().tsod_rpn_decode_f32(ptr(locs), locs.shape[-1], ptr(scores), scores.shape[-1], ptr(anchor_base), A, B,
+    check(lib().tsod_rpn_decode_f32(ptr(locs), locs.stride(0), ptr(scores), scores.stride(0), ptr(anchor_base), A, B,
                                     Hf, Wf, feat_stride, float(clamp_x), float(clamp_y), float(min_size), ptr(boxes),
                                     ptr(fg), ptr(keys), ptr(anchors), stream_ptr()), "rpn_decode")
     return boxes, fg, keys, anchors
@@ -274,13 +308,27 @@ def roi_pool_avg_nhwc(feat: torch.Tensor, rois: torch.Tensor, roi_indices: torch
     return out
 
 
+def _row_pitch(t: torch.Tensor, width: int) -> int | None:
+    """Pitch (floats) of the [B*R, width] row matrix behind a [B,R,width] tensor whose rows may be slices of a wider
+    buffer (the fused head GEMM writes both outputs into one [B*R, 408] matrix); None if it is not such a matrix."""
+    B, R, w = t.shape
+    if w != width or t.stride(2) != 1 or (B > 1 and t.stride(0) != R * t.stride(1)) or t.stride(1) < width:
+        return None
+    return t.stride(1)
+
+
 def detections(cls_locs: torch.Tensor, scores: torch.Tensor, rois: torch.Tensor) -> torch.Tensor:
     """[B,R,4*n_class], [B,R,n_class], [B,R,4] -> [B,R,6] (x1,y1,x2,y2,score,class)."""
     require_cuda(scores, "detections")
     B, R, n_class = scores.shape
+    lp, sp = _row_pitch(cls_locs, 4 * n_class), _row_pitch(scores, n_class)
+    if lp is None:
+        cls_locs, lp = cls_locs.contiguous(), 4 * n_class
+    if sp is None:
+        scores, sp = scores.contiguous(), n_class
     out = torch.empty((B, R, 6), dtype=torch.float32, device=scores.device)
-    check(lib().tsod_detections_f32(ptr(cls_locs.contiguous()), ptr(scores.contiguous()), ptr(rois.contiguous()), B * R,
-                                    n_class, ptr(out), stream_ptr()), "detections")
+    check(lib().tsod_detections_f32(ptr(cls_locs), lp, ptr(scores), sp, ptr(rois.contiguous()), B * R, n_class, ptr(out),
+                                    stream_ptr()), "detections")
     return out
 
 

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from .. import hip_ops
 from .._ffi import ACT_NONE, ACT_RELU6, TsodError, lib, ptr, require_cuda
-from ..engine import stage_input, PackedConv, Plan, fold_bn
+from ..engine import PackedConv, Plan, PlanOwner, fold_bn
 
 
 def _pad4(c: int) -> int:
@@ -159,7 +159,7 @@ class _RawConv:
         return H, W
 
 
-class HarDNetFeatureExtraction(nn.Module):
+class HarDNetFeatureExtraction(PlanOwner, nn.Module):
     def __init__(self, depth_wise=True, arch=39):
         super().__init__()
         cfg = _ARCH[arch if arch in (39, 85) else 68]          # any other value = HarDNet-68, like the reference
@@ -188,21 +188,10 @@ class HarDNetFeatureExtraction(nn.Module):
         self.base.append(nn.ReLU())
         self.base.append(nn.Conv2d(ch_list[-1], ch_list[-1], 3, 2, 1, groups=ch_list[-1]))
         self.base.append(nn.Conv2d(ch_list[-1], 512, 1, groups=512))
-        self._plans: dict = {}
+        self._init_plan_owner()
         self.out_channels = 512
 
-    # -- plan ---------------------------------------------------------------------------------
-    def invalidate_packed(self):
-        self._plans = {}
-
-    def _apply(self, fn, *a, **k):
-        self._plans = {}
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._plans = {}
-        return super().load_state_dict(*a, **k)
-
+    # -- plan (cache, invalidation, lookup: engine.PlanOwner) -----------------------------------
     @staticmethod
     def _dw_params(conv: nn.Conv2d, bn, device):
         """depthwise weights as [3][3][C_pad] + per-channel scale/shift (folded BN, or the conv bias)."""
@@ -222,7 +211,7 @@ class HarDNetFeatureExtraction(nn.Module):
         if not self.depth_wise:
             raise TsodError("depth_wise=False HarDNet (max-pool variant) has no HIP path; the reference only "
                             "uses depth_wise=True")
-        plan = Plan(device)
+        plan = Plan(device, self._packed_cache)
         L = lib()
         mods = list(self.base)
         x4 = plan.pool.alloc((N, H, W, 4))
@@ -238,17 +227,18 @@ class HarDNetFeatureExtraction(nn.Module):
             return plan.pool.alloc((N, h, w, _pad4(C))), 0
 
         def emit_dw(src, src_off, C, conv, bn, stride, relu, dst, dst_off, name):
-            w33, scale, shift, cp = self._dw_params(conv, bn, device)
+            w33, scale, shift, cp = plan.packed(name, lambda: self._dw_params(conv, bn, device))
             n, h, w_, P = src.shape
             plan.call(L.tsod_dwconv3x3_f32, ptr(src), n, h, w_, cp, P, src_off, ptr(w33), ptr(scale), ptr(shift), stride,
                       1 if relu else 0, ptr(dst), dst.shape[3], dst_off, keep=(src, dst, w33, scale, shift))
 
         # --- stem: 3x3 s2 conv (3 -> c0, input padded to 4 channels), 1x1 conv, dw3x3 s2
         m0, m1, m2 = mods[0], mods[1], mods[2]
-        pc0 = PackedConv(m0.conv.weight, device, bn=m0.norm, stride=2, pad=1, act=ACT_RELU6, cin_pad=4)
+        pc0 = plan.packed("base.0", lambda: PackedConv(m0.conv.weight, device, bn=m0.norm, stride=2, pad=1, act=ACT_RELU6,
+                                                       cin_pad=4))
         h, w = pc0.out_hw(H, W)
         t0 = plan.conv(pc0, x4, plan.pool.alloc((N, h, w, pc0.cout)), name="base.0")
-        pc1 = PackedConv(m1.conv.weight, device, bn=m1.norm, act=ACT_RELU6)
+        pc1 = plan.packed("base.1", lambda: PackedConv(m1.conv.weight, device, bn=m1.norm, act=ACT_RELU6))
         t1 = plan.conv(pc1, t0, plan.pool.alloc((N, h, w, pc1.cout)), name="base.1")
         plan.pool.release(t0)
         h2, w2 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
@@ -269,10 +259,12 @@ class HarDNetFeatureExtraction(nn.Module):
                     link = m.links[li - 1]
                     segs = [(offs[k], _pad4(real[k])) for k in link]
                     cout, cp = real[li], _pad4(real[li])
-                    wg = _gathered_weight(comb.layer1.conv.weight, [real[k] for k in link], cp)
-                    sc, sh = fold_bn(comb.layer1.norm)
-                    rc = _RawConv(wg, _padded(sc, cp), _padded(sh, cp), device, ACT_RELU6,
-                                  cin_real=sum(real[k] for k in link), cout_real=cout)
+                    def make_layer1(comb=comb, link=link, cp=cp, cout=cout):
+                        wg = _gathered_weight(comb.layer1.conv.weight, [real[k] for k in link], cp)
+                        sc, sh = fold_bn(comb.layer1.norm)
+                        return _RawConv(wg, _padded(sc, cp), _padded(sh, cp), device, ACT_RELU6,
+                                        cin_real=sum(real[k] for k in link), cout_real=cout)
+                    rc = plan.packed(f"base.{i}.layers.{li - 1}.layer1", make_layer1)
                     tmp = plan.pool.alloc((N, h, w, cp))
                     plan.conv(rc, buf, tmp, segs=segs, name=f"base.{i}.layers.{li - 1}.layer1")
                     emit_dw(tmp, 0, cout, comb.layer2.dwconv, comb.layer2.norm, 1, False, buf, offs[li],
@@ -284,9 +276,11 @@ class HarDNetFeatureExtraction(nn.Module):
                 if isinstance(mods[i], nn.Dropout):
                     i += 1
                 tr = mods[i]
-                wg = _gathered_weight(tr.conv.weight, [real[k] for k in outs], tr.conv.weight.shape[0])
-                sc, sh = fold_bn(tr.norm)
-                rc = _RawConv(wg, sc, sh, device, ACT_RELU6, cin_real=sum(real[k] for k in outs))
+                def make_transition(tr=tr, outs=outs):
+                    wg = _gathered_weight(tr.conv.weight, [real[k] for k in outs], tr.conv.weight.shape[0])
+                    sc, sh = fold_bn(tr.norm)
+                    return _RawConv(wg, sc, sh, device, ACT_RELU6, cin_real=sum(real[k] for k in outs))
+                rc = plan.packed(f"base.{i}", make_transition)
                 dst, dst_off = dest_for(i + 1, rc.cout, h, w)
                 if isinstance(mods[i + 1], DWConvLayer):          # "downsample" dw3x3 at stride 1 follows
                     plan.pool.release(dst)
@@ -313,8 +307,9 @@ class HarDNetFeatureExtraction(nn.Module):
             elif isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and m.groups == m.out_channels \
                     and m.in_channels == 2 * m.out_channels:
                 G = m.out_channels
-                wg = m.weight.detach().float().view(G, 2).contiguous().to(device)
-                bias = None if m.bias is None else m.bias.detach().float().to(device)
+                wg, bias = plan.packed(f"base.{i}", lambda m=m: (
+                    m.weight.detach().float().view(G, 2).contiguous().to(device),
+                    None if m.bias is None else m.bias.detach().float().to(device)))
                 dst = plan.pool.alloc((N, h, w, G))
                 plan.call(L.tsod_gconv1x1_pair_f32, ptr(cur), N * h * w, G, cur.shape[3], ptr(wg), ptr(bias), ptr(dst), G,
                           keep=(cur, dst, wg, bias))
@@ -325,43 +320,6 @@ class HarDNetFeatureExtraction(nn.Module):
                 raise TsodError(f"no HIP lowering for base.{i}: {type(m).__name__}")
         plan.output_nhwc = cur
         return plan.finalize()
-
-    def _plan_for(self, x, slot: int = 0):
-        require_cuda(x, "HarDNetFeatureExtraction.forward")
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise TsodError(f"expected [N,3,H,W], got {tuple(x.shape)}")
-        key = (tuple(x.shape), x.device, slot)       # slot: independent buffer sets for forwards in flight concurrently
-        plan = self._plans.get(key)
-        if plan is None:
-            if self.training:
-                raise TsodError("the HIP path implements the inference forward only: call .eval() first")
-            plan = self.build_plan(x.shape[0], x.shape[2], x.shape[3], x.device)
-            self._plans[key] = plan
-        return plan
-
-    def forward_nhwc(self, x, slot: int = 0):
-        """[N,3,H,W] (or NHWC4Images) -> NHWC feature map (plan-owned buffer, valid until the next forward)."""
-        plan = self._plan_for(x, slot)
-        stage_input(plan, x)
-        plan.run()
-        return plan.output_nhwc
-
-    def input_buffer(self, N, H, W, device, slot: int = 0):
-        """The plan's own input buffer for [N,3,H,W] images as ``NHWC4Images``: an input pipeline that writes there
-        (dataset.transform.EvalTransform.batch(..., out=...)) hands its result to the first conv without any copy."""
-        from .._ffi import NHWC4Images
-        device = torch.device(device)
-        if device.type != "cuda":
-            raise TsodError("input_buffer: a CUDA/ROCm device is required")
-        if device.index is None:
-            device = torch.device("cuda", torch.cuda.current_device())
-        key = ((N, 3, H, W), device, slot)
-        plan = self._plans.get(key)
-        if plan is None:
-            if self.training:
-                raise TsodError("the HIP path implements the inference forward only: call .eval() first")
-            plan = self._plans[key] = self.build_plan(N, H, W, device)
-        return NHWC4Images(plan.input_nhwc)
 
     def forward(self, x):
         return hip_ops.nhwc_to_nchw(self.forward_nhwc(x))

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import hip_ops
 from .._ffi import ACT_NONE, ACT_PRELU, TsodError, lib, ptr, require_cuda
-from ..engine import stage_input, PackedConv, Plan, prelu_slope
+from ..engine import PackedConv, Plan, PlanOwner, prelu_slope
 
 
 def _conv(cin, cout, k, stride=1, pad=0, groups=1):
@@ -36,7 +36,8 @@ class _ResidualBlock(nn.Module):
         identity = x
         if self.downsample is not None:
             ds_conv, ds_bn = self.downsample[0], self.downsample[1]
-            pc = PackedConv(ds_conv.weight, dev, bn=ds_bn, stride=ds_conv.stride[0], act=ACT_NONE)
+            pc = plan.packed(f"{name}.downsample", lambda: PackedConv(ds_conv.weight, dev, bn=ds_bn, stride=ds_conv.stride[0],
+                                                                      act=ACT_NONE))
             oh, ow = pc.out_hw(x.shape[1], x.shape[2])
             identity = plan.conv(pc, x, plan.pool.alloc((x.shape[0], oh, ow, pc.cout)), name=f"{name}.downsample")
         cur = x
@@ -45,7 +46,8 @@ class _ResidualBlock(nn.Module):
             conv, bn = getattr(self, cname), getattr(self, bname)
             if conv.groups != 1:
                 raise TsodError("grouped 3x3 convolutions (ResNeXt) have no HIP kernel in this build")
-            pc = PackedConv(conv.weight, dev, bn=bn, stride=conv.stride[0], pad=conv.padding[0], act=ACT_PRELU, slope=slope)
+            pc = plan.packed(f"{name}.{cname}", lambda conv=conv, bn=bn: PackedConv(
+                conv.weight, dev, bn=bn, stride=conv.stride[0], pad=conv.padding[0], act=ACT_PRELU, slope=slope))
             oh, ow = pc.out_hw(cur.shape[1], cur.shape[2])
             out = plan.pool.alloc((cur.shape[0], oh, ow, pc.cout))
             plan.conv(pc, cur, out, residual=identity if i == last else None, name=f"{name}.{cname}")
@@ -88,7 +90,7 @@ class Bottleneck(_ResidualBlock):
         self.downsample = downsample
 
 
-class ResNet(nn.Module):
+class ResNet(PlanOwner, nn.Module):
     def __init__(self, block, blocks_num, num_classes=25, include_top=True, groups=1, width_per_group=64):
         super().__init__()
         self.include_top = include_top
@@ -107,7 +109,7 @@ class ResNet(nn.Module):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
-        self._plans: dict = {}
+        self._init_plan_owner()
         self.out_channels = 512 * block.expansion
 
     def _make_layer(self, block, channel, block_num, stride=1):
@@ -122,27 +124,15 @@ class ResNet(nn.Module):
                    for _ in range(1, block_num)]
         return nn.Sequential(*blocks)
 
-    # -- plan ---------------------------------------------------------------------------------
-    def invalidate_packed(self):
-        """Drop compiled plans (call after changing weights in place)."""
-        self._plans = {}
-
-    def _apply(self, fn, *a, **k):
-        self._plans = {}
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._plans = {}
-        return super().load_state_dict(*a, **k)
-
+    # -- plan (cache, invalidation, lookup: engine.PlanOwner) -----------------------------------
     def build_plan(self, N, H, W, device) -> Plan:
         """Launch plan for a [N,3,H,W] input: NCHW->NHWC4, 7x7 stem as a 7x8x4 implicit GEMM with
         BN+PReLU, 3x3/s2 max pool, then the residual stages."""
-        plan = Plan(device)
+        plan = Plan(device, self._packed_cache)
         x4 = plan.pool.alloc((N, H, W, 4))
         plan.input_nhwc = x4
-        stem = PackedConv(self.conv1.weight, device, bn=self.bn1, stride=2, pad=3, act=ACT_PRELU,
-                          slope=prelu_slope(self.relu), cin_pad=4, kw_pad=8)
+        stem = plan.packed("conv1", lambda: PackedConv(self.conv1.weight, device, bn=self.bn1, stride=2, pad=3, act=ACT_PRELU,
+                                                       slope=prelu_slope(self.relu), cin_pad=4, kw_pad=8))
         oh, ow = stem.out_hw(H, W)
         s_out = plan.conv(stem, x4, plan.pool.alloc((N, oh, ow, 64)), name="conv1")
         ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
@@ -156,43 +146,6 @@ class ResNet(nn.Module):
                 cur = nxt
         plan.output_nhwc = cur
         return plan.finalize()
-
-    def _plan_for(self, x: torch.Tensor, slot: int = 0) -> Plan:
-        require_cuda(x, "ResNet.forward")
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise TsodError(f"expected [N,3,H,W], got {tuple(x.shape)}")
-        key = (tuple(x.shape), x.device, slot)       # slot: independent buffer sets for forwards in flight concurrently
-        plan = self._plans.get(key)
-        if plan is None:
-            if self.training:
-                raise TsodError("the HIP path implements the inference forward only: call .eval() first")
-            plan = self.build_plan(x.shape[0], x.shape[2], x.shape[3], x.device)
-            self._plans[key] = plan
-        return plan
-
-    def forward_nhwc(self, x: torch.Tensor, slot: int = 0) -> torch.Tensor:
-        """[N,3,H,W] (or NHWC4Images) -> NHWC feature map (plan-owned buffer, valid until the next forward)."""
-        plan = self._plan_for(x, slot)
-        stage_input(plan, x)
-        plan.run()
-        return plan.output_nhwc
-
-    def input_buffer(self, N, H, W, device, slot: int = 0):
-        """The plan's own input buffer for [N,3,H,W] images as ``NHWC4Images``: an input pipeline that writes there
-        (dataset.transform.EvalTransform.batch(..., out=...)) hands its result to the first conv without any copy."""
-        from .._ffi import NHWC4Images
-        device = torch.device(device)
-        if device.type != "cuda":
-            raise TsodError("input_buffer: a CUDA/ROCm device is required")
-        if device.index is None:
-            device = torch.device("cuda", torch.cuda.current_device())
-        key = ((N, 3, H, W), device, slot)
-        plan = self._plans.get(key)
-        if plan is None:
-            if self.training:
-                raise TsodError("the HIP path implements the inference forward only: call .eval() first")
-            plan = self._plans[key] = self.build_plan(N, H, W, device)
-        return NHWC4Images(plan.input_nhwc)
 
     def forward(self, x):
         feat = self.forward_nhwc(x)

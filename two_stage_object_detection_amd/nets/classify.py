@@ -1,8 +1,9 @@
 """RoI head with the reference's module surface (nets/classify.py) on HIP kernels.
 
 RoI rescale + image index + RoIPool 7x7 + the classifier's 7x7 mean are one kernel
-(tsod_roi_pool_avg_f32: the [K,C,7,7] pooled tensor is never materialised); the two nn.Linear layers
-run on the f32 MFMA GEMM.  Works for any batch size and any RoIs/image (the reference hard-codes 128
+(tsod_roi_pool_avg_f32: the [K,C,7,7] pooled tensor is never materialised); the two nn.Linear layers run as ONE
+f32 MFMA GEMM (N = 4*n_class + n_class = 405 padded to 408: wide epilogue stores), whose two column ranges are
+returned as views.  Works for any batch size and any RoIs/image (the reference hard-codes 128
 RoIs and batch 1: quirk Q5).  ``in_channels`` generalises the reference's hard-coded 512.
 """
 from __future__ import annotations
@@ -12,6 +13,7 @@ from torch import nn
 
 from .. import hip_ops
 from .._ffi import TsodError, require_cuda
+from ..engine import PlanOwner
 from ..models.hardnet import HarNetClassifier
 
 
@@ -28,13 +30,28 @@ class RoIPool(nn.Module):
         return hip_ops.roi_pool_nhwc(hip_ops.nchw_to_nhwc(x), rois, self.output_size, self.spatial_scale)
 
 
-class HarNetRoIHead(nn.Module):
+class HarNetRoIHead(PlanOwner, nn.Module):
     def __init__(self, n_class, roi_size, spatial_scale, classifier, in_channels=512):
         super().__init__()
         self.classifier = classifier
         self.cls_loc = nn.Linear(in_channels, n_class * 4)
         self.score = nn.Linear(in_channels, n_class)
         self.roi = RoIPool((roi_size, roi_size), spatial_scale)
+        self._init_plan_owner()
+
+    def _pack(self, dev):
+        """(weight [pad4(5*n_class), C], bias, 4*n_class, n_class) on ``dev``: cls_loc rows, then score rows
+        (nets/classify.py:13,15), zero rows up to a multiple of 4."""
+        ent = self._packed_cache.get(("head", dev))
+        if ent is None:
+            n_loc, n_sc = self.cls_loc.out_features, self.score.out_features
+            n_pad = (n_loc + n_sc + 3) // 4 * 4
+            w = torch.zeros((n_pad, self.cls_loc.in_features), dtype=torch.float32)
+            b = torch.zeros(n_pad, dtype=torch.float32)
+            w[:n_loc], w[n_loc:n_loc + n_sc] = self.cls_loc.weight.detach().float().cpu(), self.score.weight.detach().float().cpu()
+            b[:n_loc], b[n_loc:n_loc + n_sc] = self.cls_loc.bias.detach().float().cpu(), self.score.bias.detach().float().cpu()
+            ent = self._packed_cache[("head", dev)] = (w.to(dev).contiguous(), b.to(dev), n_loc, n_sc)
+        return ent
 
     def forward_nhwc(self, feat, rois, roi_indices, img_size):
         """feat NHWC [n,Hf,Wf,C]; rois [n,R,4] image coords; roi_indices [n]; img_size (H,W) (quirk Q2)."""
@@ -45,9 +62,11 @@ class HarNetRoIHead(nn.Module):
         rois = rois.reshape(n, -1, 4)
         fc7 = hip_ops.roi_pool_avg_nhwc(feat, rois, roi_indices, img_size[0], img_size[1], self.roi.output_size,
                                         self.roi.spatial_scale)
-        roi_cls_locs = hip_ops.linear(fc7, self.cls_loc.weight, self.cls_loc.bias)
-        roi_scores = hip_ops.linear(fc7, self.score.weight, self.score.bias)
-        return roi_cls_locs.view(n, -1, roi_cls_locs.size(1)), roi_scores.view(n, -1, roi_scores.size(1))
+        w, b, n_loc, n_sc = self._pack(feat.device)
+        both = hip_ops.linear(fc7, w, b)                       # [n*R, pad4(5*n_class)]
+        # views into the fused output (row pitch 408 for 81 classes): same values and shapes as the reference's two
+        # Linear outputs; .contiguous() them if a consumer needs dense storage
+        return both[:, :n_loc].view(n, -1, n_loc), both[:, n_loc:n_loc + n_sc].view(n, -1, n_sc)
 
     def forward(self, x, rois, roi_indices, img_size):
         """x NCHW [n,C,Hf,Wf] (the reference's layout)."""

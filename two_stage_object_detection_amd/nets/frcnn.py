@@ -13,6 +13,8 @@ Added, non-breaking: ``backbone`` = "hardnet39" (the reference's default extract
 """
 from __future__ import annotations
 
+import itertools
+
 import torch
 import torch.nn as nn
 
@@ -21,6 +23,9 @@ from .._ffi import TsodError, require_cuda
 from .classify import HarNetRoIHead
 from .rpn import RegionProposalNetwork
 from ..models.hardnet import HarDNetFeatureExtraction, HarNetClassifier
+
+
+_UID = itertools.count(1)
 
 
 def _make_extractor(backbone):
@@ -45,6 +50,16 @@ class FasterRCNN(nn.Module):
                                          feat_stride=self.feat_stride, mode=mode)
         self.head = HarNetRoIHead(n_class=num_classes + 1, roi_size=7, spatial_scale=1, classifier=self.classifier,
                                   in_channels=feat_ch)
+        self.__dict__["_uid"] = next(_UID)          # scratch ownership: (this detector, slot), see hip_ops._Arena
+
+    def weights_version(self):
+        """Changes whenever packed weights were invalidated (load_state_dict / .to() / invalidate_packed)."""
+        return (self.extractor.weights_version, self.rpn.weights_version, self.head.weights_version)
+
+    def invalidate_packed(self):
+        """Call after editing parameters in place: drops every packed weight / plan of the detector."""
+        for m in (self.extractor, self.rpn, self.head):
+            m.invalidate_packed()
 
     def _roi_indices(self, n, device):
         """arange(B) int32 (frcnn_training.py:291), cached per (B, device): a constant, not a per-forward launch."""
@@ -59,10 +74,11 @@ class FasterRCNN(nn.Module):
         different HIP streams can be in flight together."""
         if mode == "forward":
             require_cuda(x, "FasterRCNN.forward")
-            feat = self.extractor.forward_nhwc(x, slot)
-            _, _, rois, _ = self.rpn.forward_nhwc(feat, tuple(x.shape[1:]), scale)
-            roi_indices = self._roi_indices(x.shape[0], x.device)
-            roi_cls_locs, roi_scores = self.head.forward_nhwc(feat, rois, roi_indices, tuple(x.shape[2:]))
+            with hip_ops.ARENA.scope((self._uid, slot)):          # scratch owned by (detector, slot), not by the stream
+                feat = self.extractor.forward_nhwc(x, slot)
+                _, rois, _ = self.rpn.propose(feat, tuple(x.shape[1:]), scale)
+                roi_indices = self._roi_indices(x.shape[0], x.device)
+                roi_cls_locs, roi_scores = self.head.forward_nhwc(feat, rois, roi_indices, tuple(x.shape[2:]))
             return roi_cls_locs, roi_scores, rois, roi_indices
         elif mode == "extractor":
             return self.extractor.forward(x)
@@ -114,7 +130,8 @@ class FasterRCNN(nn.Module):
         return [det_sorted[b][keep[b, :ns[b]].long()] for b in range(det.shape[0])]
 
     def make_graphed(self, x_example, slot=0):
-        """Capture forward + detection records for this input geometry into ONE HIP graph.
+        """Capture forward + detection records for this input geometry into ONE HIP graph (rebuild it after a weight
+        change: ``run`` raises once the weights it was captured with have been invalidated).
         Returns (run, static_input, static_outputs): copy images into ``static_input`` (or pass them
         to ``run(x)``), call ``run()``, read ``static_outputs`` = (roi_cls_locs, roi_scores, rois,
         roi_indices, detections).  torch.cuda.CUDAGraph is only the stream-capture plumbing: every
@@ -134,13 +151,19 @@ class FasterRCNN(nn.Module):
             outs = self.forward(static_in, slot=slot)
             det = hip_ops.detections(outs[0], outs[1], outs[2])
         static_out = tuple(outs) + (det,)
+        version = self.weights_version()
+        plan = self.extractor._plan_for(static_in, slot)       # the graph's buffers live as long as the closure does
 
         def run(x=None):
+            if self.weights_version() != version:
+                raise TsodError("the detector's weights changed after this graph was captured (load_state_dict / .to() / "
+                                "invalidate_packed): it would replay the old folded weights - call make_graphed() again")
             if x is not None:
                 with torch.inference_mode():                    # static_in may have been created under inference mode
                     static_in.copy_(x, non_blocking=True)
             graph.replay()
             return static_out
+        run.plan = plan
         return run, static_in, static_out
 
     def raise_if_error(self):

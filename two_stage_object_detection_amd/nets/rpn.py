@@ -6,8 +6,8 @@ behaviour (Q3), the img_size[1] / img_size[2] clamp indexing (Q1) and the duplic
 after NMS (Q4).  The per-image Python loop of the reference (nets/rpn.py:129-137) is replaced by
 batched kernels:
 
-    1x1 convs (implicit GEMM, NHWC out)  ->  tsod_rpn_decode_f32  ->  tsod_sort_topk_desc_f32
-    ->  tsod_nms_f32 (mask + wave scan + pad)
+    ONE 1x1 conv GEMM for loc + score (N = 4A + 2A = 54 padded to 56: wide epilogue stores, NHWC out)
+    ->  tsod_rpn_decode_f32  ->  tsod_sort_topk_desc_f32  ->  tsod_nms_f32 (mask + wave scan + pad)
 
 Nothing in the chain synchronises with the host.  The one error the reference can raise here
 (IndexError when the pad needs more candidates than exist) is recorded in a device status word:
@@ -20,7 +20,7 @@ from torch import nn
 
 from .. import hip_ops
 from .._ffi import ACT_NONE, TsodError, require_cuda
-from ..engine import PackedConv
+from ..engine import PackedConv, PlanOwner
 from ..utils._config import load_config
 from ..utils.basic_anchors import generate_basic_anchor
 
@@ -79,7 +79,7 @@ class ProposalCreator:
         return self.select(boxes.unsqueeze(0), keys.unsqueeze(0))[0]
 
 
-class RegionProposalNetwork(nn.Module):
+class RegionProposalNetwork(PlanOwner, nn.Module):
     def __init__(self, in_channels=512, ratios=[0.5, 1, 2], anchor_scales=[8, 16, 32], feat_stride=16,
                  mode="training"):
         super().__init__()
@@ -93,40 +93,46 @@ class RegionProposalNetwork(nn.Module):
         self.feat_stride = feat_stride
         self.proposal_layer = ProposalCreator(mode)
         self.proposal_layer.strict = False
-        self._packed = None
-
-    def _apply(self, fn, *a, **k):
-        self._packed = None
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._packed = None
-        return super().load_state_dict(*a, **k)
-
-    def invalidate_packed(self):
-        self._packed = None
+        self._init_plan_owner()
 
     def _pack(self, dev):
-        if self._packed is None or self._packed[0] != dev:
-            self._packed = (dev,
-                            PackedConv(self.loc.weight, dev, bias=self.loc.bias, act=ACT_NONE),
-                            PackedConv(self.score.weight, dev, bias=self.score.bias, act=ACT_NONE),
-                            torch.as_tensor(self.anchor_base, dtype=torch.float32).to(dev).contiguous())
-        return self._packed[1:]
+        """(fused conv, base anchors, 4A, 2A) on ``dev``: the loc and score convs (nets/rpn.py:86-88) stacked into one
+        [4A + 2A (+ pad to a multiple of 4), C] weight: rows [0,4A) = loc, [4A,6A) = score, zero rows after."""
+        ent = self._packed_cache.get(("rpn", dev))
+        if ent is None:
+            n_loc, n_sc = self.loc.out_channels, self.score.out_channels
+            cout = (n_loc + n_sc + 3) // 4 * 4
+            w = torch.zeros((cout,) + tuple(self.loc.weight.shape[1:]), dtype=torch.float32)
+            b = torch.zeros(cout, dtype=torch.float32)
+            w[:n_loc], w[n_loc:n_loc + n_sc] = self.loc.weight.detach().float().cpu(), self.score.weight.detach().float().cpu()
+            b[:n_loc], b[n_loc:n_loc + n_sc] = self.loc.bias.detach().float().cpu(), self.score.bias.detach().float().cpu()
+            ent = self._packed_cache[("rpn", dev)] = (
+                PackedConv(w.to(dev), dev, bias=b, act=ACT_NONE),
+                torch.as_tensor(self.anchor_base, dtype=torch.float32).to(dev).contiguous(), n_loc, n_sc)
+        return ent
+
+    def propose(self, feat: torch.Tensor, img_size, scale=1., want_anchors=False):
+        """feat NHWC [n,h,w,C] -> (fused conv output [n*h*w, pad4(6A)] with loc in columns [0,4A) and score in
+        [4A,6A), rois [n,n_post,4], anchors [h*w*A,4] or None).  Four launches, no host sync."""
+        require_cuda(feat, "RegionProposalNetwork")
+        n, h, w, _ = feat.shape
+        pc, base, n_loc, n_sc = self._pack(feat.device)
+        fused = hip_ops.conv2d_nhwc(feat, pc.w, shift=pc.shift).view(n * h * w, pc.cout)
+        boxes, _, keys, anchor = hip_ops.rpn_decode(fused[:, :n_loc], fused[:, n_loc:n_loc + n_sc], base, n, h, w,
+                                                    self.feat_stride, img_size[1], img_size[2],
+                                                    self.proposal_layer.min_size * scale, want_anchors=want_anchors)
+        return fused, self.proposal_layer.select(boxes, keys), anchor
 
     def forward_nhwc(self, feat: torch.Tensor, img_size, scale=1.):
         """feat NHWC [n,h,w,C] -> (rpn_locs [n,h*w*A,4], rpn_scores [n,h*w*A,2], rois [n,n_post,4], anchor [1,h*w*A,4])."""
-        require_cuda(feat, "RegionProposalNetwork")
-        n, h, w, _ = feat.shape
-        pc_loc, pc_score, base = self._pack(feat.device)
-        locs = hip_ops.conv2d_nhwc(feat, pc_loc.w, shift=pc_loc.shift)        # [n,h,w,4A]: already the permuted layout
-        scores = hip_ops.conv2d_nhwc(feat, pc_score.w, shift=pc_score.shift)  # [n,h,w,2A]
-        A = base.shape[0]
-        boxes, _, keys, anchor = hip_ops.rpn_decode(locs.view(n * h * w, 4 * A), scores.view(n * h * w, 2 * A), base, n, h,
-                                                    w, self.feat_stride, img_size[1], img_size[2],
-                                                    self.proposal_layer.min_size * scale, want_anchors=True)
-        rois = self.proposal_layer.select(boxes, keys)
-        return locs.view(n, -1, 4), scores.view(n, -1, 2), rois, anchor.unsqueeze(0)
+        n = feat.shape[0]
+        fused, rois, anchor = self.propose(feat, img_size, scale, want_anchors=True)
+        _, _, n_loc, n_sc = self._pack(feat.device)
+        # the reference returns contiguous [n, h*w*A, 4] / [n, h*w*A, 2] tensors (its permute + view, nets/rpn.py:108,113):
+        # two strided copies out of the fused buffer (memory plumbing; the detector forward never asks for them)
+        locs = fused[:, :n_loc].contiguous().view(n, -1, 4)
+        scores = fused[:, n_loc:n_loc + n_sc].contiguous().view(n, -1, 2)
+        return locs, scores, rois, anchor.unsqueeze(0)
 
     def forward(self, x, img_size, scale=1.):
         """x NCHW [n,C,h,w] (the reference's layout)."""

@@ -4,7 +4,8 @@ A batch-1 forward of a two-stage detector is a chain of ~60 small launches; many
 workgroup top-k / NMS scans) cannot fill 256 CUs on their own.  ``InFlightDetector`` keeps ``depth`` independent copies
 of the step (own HIP graph, own backbone buffers and scratch: ``FasterRCNN.make_graphed(x, slot)``) and issues
 consecutive requests round-robin on ``depth`` HIP streams, so the tail of one forward overlaps the next one's kernels.
-Every request still executes the whole path; nothing is shared between slots but the (read-only) weights.
+Every request still executes the whole path; nothing is shared between slots but the (read-only) packed weights
+(one copy per layer and device, engine.PlanOwner); scratch is owned per (detector, slot), not per stream handle.
 
 This is what ``bench.py`` measures by default (``--in-flight 4``): ~585 images/s against ~420 strictly serial at batch 1
 on MI355X.  Depth 2 already gives ~540; depths 3-8 are equivalent.

@@ -8,7 +8,7 @@ import torch
 
 
 def synthetic_detector(backbone="resnet50", num_classes=80, seed=0, mode="training", rpn_loc_gain=None,
-                       rpn_score_gain=None, head_gain=None, calibrate_hw=None):
+                       rpn_score_gain=None, head_gain=None):
     """The detector with seeded random-init weights of the reference architecture:
     ``torch.manual_seed(seed)`` then modules constructed in reference order (ResNet: Kaiming fan_out on
     every conv, BN identity, PReLU 0.25; HarDNet / RPN / head: PyTorch defaults).
