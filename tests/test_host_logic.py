@@ -169,3 +169,28 @@ def test_plan_cache_is_lru_bounded():
     m.drop_plan(shape=(1, 3, 128, 64))
     assert list(m._plans.values()) == ["plan4", "plan2"]
     assert isinstance(m._plans, OrderedDict)
+
+
+def test_weight_cache_hash_and_plain_data_roundtrip(tmp_path):
+    """weight_cache.py on the CPU: the key is a content hash of the state_dict (any changed value or name changes it),
+    and packed entries serialise to plain data that torch.load(weights_only=True) accepts."""
+    from two_stage_object_detection_amd import weight_cache as wc
+    from two_stage_object_detection_amd.engine import PackedConv
+    torch.manual_seed(1)
+    m = FasterRCNN(num_classes=3).eval()
+    h0 = wc.state_dict_hash(m.state_dict())
+    assert h0 == wc.state_dict_hash({k: v.clone() for k, v in m.state_dict().items()}) and len(h0) == 32
+    with torch.no_grad():
+        m.head.score.bias[0] += 1e-3
+    assert wc.state_dict_hash(m.state_dict()) != h0
+    pc = PackedConv.__new__(PackedConv)
+    pc.w, pc.scale, pc.shift = torch.randn(8, 1, 1, 4), None, torch.randn(8)
+    pc.cout, pc.cin_src, pc.kh, pc.kw_logical, pc.cin, pc.kw, pc.stride, pc.pad, pc.act, pc.slope = 8, 3, 1, 1, 4, 1, 1, 0, 1, 0.25
+    entry = (pc, torch.arange(4.0), 36, 18)
+    path = tmp_path / "x.pt"
+    torch.save({"e": wc._to_state(entry)}, path)
+    back = wc._from_state(torch.load(path, weights_only=True)["e"], "cpu")
+    assert isinstance(back, tuple) and isinstance(back[0], PackedConv) and back[2:] == (36, 18)
+    assert torch.equal(back[0].w, pc.w) and back[0].scale is None and back[0].slope == 0.25 and back[0].out_hw(5, 7) == (5, 7)
+    assert wc.cache_path(str(tmp_path), m).endswith(f"hardnet39-{wc.state_dict_hash(m.state_dict())}.tsodpack")
+    assert wc.load_packed(m, str(tmp_path), "cpu") is False          # nothing cached yet: the model is left alone

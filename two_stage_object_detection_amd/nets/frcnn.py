@@ -97,16 +97,29 @@ class FasterRCNN(nn.Module):
         cls_locs, scores, rois, _ = self.forward(x, scale)
         return hip_ops.detections(cls_locs, scores, rois)
 
-    def load_trainer_checkpoint(self, ckpt, strict=True):
+    def load_trainer_checkpoint(self, ckpt, strict=True, packed_cache=None):
         """Load weights saved by the reference's training script (train/train.py:120-128 writes
         ``{'model_state_dict': FasterRCNNTrainer.state_dict(), ...}``; the trainer names the backbone
         ``feat_extra`` where this module - like nets/frcnn.py:15 - says ``extractor``).  ``ckpt`` is a path
-        (loaded with weights_only=True, as train/train.py:60-71 does) or an already loaded dict."""
+        (loaded with weights_only=True, as train/train.py:60-71 does) or an already loaded dict.
+        ``packed_cache``: a directory for the on-disk cache of the packed weights (``use_packed_cache``); the module must
+        already live on its GPU."""
         if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
             ckpt = torch.load(ckpt, map_location="cpu", weights_only=True)
         sd = ckpt.get("model_state_dict", ckpt)
         remapped = {("extractor." + k[len("feat_extra."):] if k.startswith("feat_extra.") else k): v for k, v in sd.items()}
-        return self.load_state_dict(remapped, strict=strict)
+        res = self.load_state_dict(remapped, strict=strict)
+        if packed_cache is not None:
+            self.use_packed_cache(packed_cache)
+        return res
+
+    def use_packed_cache(self, directory, device=None):
+        """Fold / pack the weights once and keep the result on disk, keyed by the hash of the state_dict
+        (weight_cache.py): returns "hit" when ``directory`` held the packed form of exactly these weights (no folding,
+        gathering or packing work is done), "miss" after packing and writing it.  Call with the module on its GPU and in
+        eval mode, after the weights are final (``.to()`` and ``load_state_dict`` drop packed weights)."""
+        from .. import weight_cache
+        return weight_cache.ensure_packed(self, directory, device)
 
     def postprocess(self, det, iou_threshold=0.1, score_thresh=None, per_class=False, background_class=-1):
         """The inference-time filtering of the reference's demo script (multi_inference.py:80-87): per image,
