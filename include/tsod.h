@@ -251,6 +251,32 @@ int tsod_detection_nms_f32(const float *det_sorted, const int32_t *counts, int32
                            int32_t per_class, int32_t *keep_idx, int32_t *n_kept, void *workspace,
                            size_t workspace_bytes, tsod_stream_t stream);
 
+/* ---- training-side box ops ---------------------------------------------------------------
+ * The reference's two target creators are deterministic IoU arg-max assignments ("first n by index" sampling); both are
+ * restated with their indexing quirks (oracle/targets.py T1-T4).  IoU is utils/loc_bbox_iou.py:4-27 (eps 1e-8), offsets
+ * are bbox2loc (utils/loc_bbox_iou.py:63-88).
+ *
+ * tsod_anchor_targets_f32 = AnchorTargetCreator(n_sample, pos_iou_thresh, neg_iou_thresh, pos_ratio)(bbox, anchor),
+ * nets/frcnn_training.py:19-103, with n_pos = int(pos_ratio * n_sample) computed by the caller:
+ *   anchor [A][4], bbox [G][4] (G may be 0) ->
+ *   label  [A] int64: -1 ignore / 0 negative / 1 positive     loc [A][4]: bbox2loc(anchor, bbox[argmax]) or zeros when
+ *   argmax [A] int32: the gt index each anchor is assigned to  there is no positive
+ * tsod_proposal_targets_f32 = ProposalTargetCreator(n_sample, pos_ratio, pos_iou_thresh, neg_iou_thresh_high,
+ * neg_iou_thresh_low)(roi, bbox, label), nets/frcnn_training.py:105-177, pos_per_image = int(n_sample * pos_ratio):
+ *   roi [R][4], bbox [G][4], gt_label [G] int64 -> the first counts[0] = S <= n_sample rows of
+ *   sample_roi [n_sample][4], gt_roi_loc [n_sample][4], gt_roi_label [n_sample] int64;
+ *   counts [4] int32 = (S, kept positives, kept negatives, status): status 1 = the reference raises IndexError here
+ *   (quirk T2: a sampled negative's original index lies beyond the kept list). */
+size_t tsod_anchor_targets_workspace_bytes(int32_t A, int32_t G);
+int tsod_anchor_targets_f32(const float *anchor, int32_t A, const float *bbox, int32_t G, float pos_iou_thresh,
+                            float neg_iou_thresh, int32_t n_pos, int32_t n_sample, float *loc, int64_t *label,
+                            int32_t *argmax, void *workspace, size_t workspace_bytes, tsod_stream_t stream);
+size_t tsod_proposal_targets_workspace_bytes(int32_t R, int32_t G, int32_t n_sample);
+int tsod_proposal_targets_f32(const float *roi, int32_t R, const float *bbox, int32_t G, const int64_t *gt_label,
+                              int32_t n_sample, int32_t pos_per_image, float pos_iou_thresh, float neg_iou_thresh_high,
+                              float neg_iou_thresh_low, float *sample_roi, float *gt_roi_loc, int64_t *gt_roi_label,
+                              int32_t *counts, void *workspace, size_t workspace_bytes, tsod_stream_t stream);
+
 /* ---- input step (the step before the path) ----------------------------------------------
  * dataset/dataloader.py:35-44 + dataset/transform.py:14-17: a decoded RGB image becomes an f32 CHW tensor with
  * values 0..255 and is resized to the detector's fixed size by torchvision v2 Resize, i.e. ATen's antialiased

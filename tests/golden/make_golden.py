@@ -97,6 +97,63 @@ def extras_round2():
     save("boxmath_k.npz", src=src.numpy(), loc_k3=loc_k.numpy(), loc2bbox_k3=ref_box.loc2bbox(src, loc_k).numpy(),
          empty=ref_box.loc2bbox(torch.zeros(0, 4), torch.zeros(0, 4)).numpy())
 
+    # ---- training-side box ops: the reference's own target creators, nets/frcnn_training.py:19-177.
+    # The module imports torchvision.ops.nms (stand-in above) and reads its device from configs/config.json ("cuda:0"):
+    # patched to "cpu" after import, like nets.rpn.  Both classes are deterministic (no random sampling).
+    import nets.frcnn_training as ref_train
+    ref_train.device = "cpu"
+
+    def boxes(n, span_x, span_y, wh_lo, wh_hi):
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([span_x, span_y])
+        wh = torch.rand(n, 2, generator=g) * (wh_hi - wh_lo) + wh_lo
+        return torch.cat([xy, xy + wh], dim=1)
+
+    base = ref_anchors.generate_basic_anchor()
+    anchor = ref_anchors.enumerate_shifted_anchor(base, 16, 20, 28)                 # 5040 anchors of a 320x448 image
+    cases = {}
+    gt5 = boxes(5, 300, 200, 40, 160)
+    cases["default"] = (dict(), gt5)
+    gt_dup = torch.cat([gt5[:3], gt5[1:2], boxes(2, 300, 200, 60, 200)])            # a duplicated gt: ties + override order (T4)
+    cases["dup"] = (dict(), gt_dup)
+    cases["many_pos"] = (dict(pos_iou_thresh=0.35, neg_iou_thresh=0.2), boxes(8, 250, 150, 80, 220))   # > 128 positives: the cap
+    cases["all_pos_ratio"] = (dict(n_sample=16, pos_ratio=1.0, pos_iou_thresh=0.4), gt5)   # n_neg == 0: T1 disables all negatives
+    cases["no_gt"] = (dict(), torch.zeros(0, 4))
+    arrs = {"anchor": anchor.numpy()}
+    for name, (kw, gt) in cases.items():
+        loc, label = ref_train.AnchorTargetCreator(**kw)(gt, anchor)
+        arrs[f"{name}.bbox"] = gt.numpy()
+        arrs[f"{name}.loc"] = loc.numpy()
+        arrs[f"{name}.label"] = label.numpy()
+        arrs[f"{name}.kw"] = np.array(repr(kw))
+    save("targets_anchor.npz", **arrs)
+
+    arrs = {}
+    gt6 = boxes(6, 300, 200, 40, 160)
+    lab6 = torch.randint(0, 20, (6,), generator=g)
+    roi = boxes(300, 380, 260, 16, 200)
+    roi[::7] = gt6[torch.arange(0, 43) % 6] + torch.randn(43, 4, generator=g) * 4   # some RoIs near a gt -> positives
+    pcases = {"default": (dict(), roi, gt6, lab6),
+              "few": (dict(), roi[:60], gt6[:2], lab6[:2]),                          # fewer candidates than n_sample
+              "no_gt": (dict(), roi[:200], torch.zeros(0, 4), torch.zeros(0, dtype=torch.int64)),
+              "thresholds": (dict(n_sample=100, pos_ratio=0.3, pos_iou_thresh=0.4, neg_iou_thresh_high=0.4), roi, gt6, lab6),
+              # a gap between the thresholds: sampled negatives sit at original indices beyond the kept length -> T2 raises
+              "thresholds_gap": (dict(n_sample=64, pos_ratio=0.25, pos_iou_thresh=0.6, neg_iou_thresh_high=0.4,
+                                      neg_iou_thresh_low=0.05), roi, gt6, lab6)}
+    crowded = roi.clone()
+    crowded[:100] = gt6[torch.arange(0, 100) % 6] + torch.randn(100, 4, generator=g) * 2   # > 64 positives up front: T2 raises
+    pcases["index_error"] = (dict(), crowded, gt6, lab6)
+    for name, (kw, r, gt, lab) in pcases.items():
+        arrs[f"{name}.roi"], arrs[f"{name}.bbox"], arrs[f"{name}.label"] = r.numpy(), gt.numpy(), lab.numpy()
+        arrs[f"{name}.kw"] = np.array(repr(kw))
+        try:
+            s_roi, s_loc, s_lab = ref_train.ProposalTargetCreator(**kw)(r, gt, lab)
+            arrs[f"{name}.raises"] = np.array(False)
+            arrs[f"{name}.sample_roi"], arrs[f"{name}.gt_roi_loc"], arrs[f"{name}.gt_roi_label"] = \
+                s_roi.numpy(), s_loc.numpy(), s_lab.numpy()
+        except IndexError:
+            arrs[f"{name}.raises"] = np.array(True)
+    save("targets_proposal.npz", **arrs)
+
 
 @torch.inference_mode()
 def main():

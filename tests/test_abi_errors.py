@@ -102,3 +102,20 @@ def test_status_strings():
     seen = {L.tsod_status_str(c) for c in range(0, -6, -1)}
     assert len(seen) == 6 and all(isinstance(s, bytes) and s for s in seen)
     assert L.tsod_status_str(-99) == b"unknown status"
+
+
+def test_target_creator_validation():
+    L = lib()
+    assert L.tsod_anchor_targets_f32(None, 10, P, 2, 0.7, 0.3, 128, 256, P, P, P, P, 1 << 20, None) == INVALID
+    assert L.tsod_anchor_targets_f32(P, 0, P, 2, 0.7, 0.3, 128, 256, P, P, P, P, 1 << 20, None) == INVALID
+    assert L.tsod_anchor_targets_f32(P, 10, None, 2, 0.7, 0.3, 128, 256, P, P, P, P, 1 << 20, None) == INVALID   # G > 0 needs boxes
+    assert L.tsod_anchor_targets_f32(ODD, 10, P, 2, 0.7, 0.3, 128, 256, P, P, P, P, 1 << 20, None) == ALIGNMENT
+    assert L.tsod_anchor_targets_f32(P, 10, P, 2, 0.7, 0.3, 128, 256, P, P, P, P, 8, None) == WORKSPACE
+    assert L.tsod_anchor_targets_f32(P, 10, P, 2, 0.7, 0.3, 128, 256, P, P, P, None, 0, None) == WORKSPACE
+    assert L.tsod_proposal_targets_f32(P, 0, P, 0, P, 128, 64, 0.5, 0.5, 0.0, P, P, P, P, P, 1 << 20, None) == INVALID
+    assert L.tsod_proposal_targets_f32(P, 10, P, 2, None, 128, 64, 0.5, 0.5, 0.0, P, P, P, P, P, 1 << 20, None) == INVALID
+    assert L.tsod_proposal_targets_f32(P, 10, P, 2, P, 0, 64, 0.5, 0.5, 0.0, P, P, P, P, P, 1 << 20, None) == INVALID
+    assert L.tsod_proposal_targets_f32(P, 10, P, 2, P, 128, 64, 0.5, 0.5, 0.0, P, P, P, P, P, 16, None) == WORKSPACE
+    assert L.tsod_anchor_targets_workspace_bytes(37800, 20) >= 37800 * 4 + 80
+    assert L.tsod_proposal_targets_workspace_bytes(600, 20, 128) >= 2 * 620 * 4 + 512
+    assert L.tsod_anchor_targets_workspace_bytes(0, 3) == 0 and L.tsod_proposal_targets_workspace_bytes(0, 0, 128) == 0

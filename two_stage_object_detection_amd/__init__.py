@@ -25,7 +25,7 @@ def install_dropin(force: bool = False) -> None:
     """Register ``nets``, ``models``, ``utils`` and ``dataset`` (and their sub-modules) as aliases of this package's
     mirrors of the reference modules."""
     for top, subs in (("utils", ("basic_anchors", "loc_bbox_iou")), ("models", ("resnet", "hardnet")),
-                      ("nets", ("rpn", "classify", "frcnn")), ("dataset", ("transform",))):
+                      ("nets", ("rpn", "classify", "frcnn", "frcnn_training")), ("dataset", ("transform",))):
         if top in sys.modules and not force and not getattr(sys.modules[top], "__tsod_dropin__", False):
             raise ImportError(f"a different top-level package named {top!r} is already imported")
         pkg = importlib.import_module(f"{__name__}.{top}")

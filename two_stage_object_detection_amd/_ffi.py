@@ -84,6 +84,12 @@ _SIGNATURES = {
     "tsod_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "tsod_detection_nms_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p, c_void_p, c_void_p,
                                        c_size_t, c_void_p]),
+    "tsod_anchor_targets_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "tsod_anchor_targets_f32": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_float, c_float, c_int32, c_int32, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tsod_proposal_targets_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "tsod_proposal_targets_f32": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_float, c_float,
+                                          c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

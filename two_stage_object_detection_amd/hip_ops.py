@@ -362,6 +362,47 @@ def filter_detections(det: torch.Tensor, iou_thr: float = 0.1, score_thresh: flo
     return det_sorted, keep, n_kept
 
 
+# ----------------------------------------------------------------------------- training-side box ops
+def anchor_targets(bbox: torch.Tensor, anchor: torch.Tensor, n_pos: int, n_sample: int, pos_iou_thresh: float,
+                   neg_iou_thresh: float):
+    """anchor [A,4], bbox [G,4] -> (loc [A,4] f32, label [A] int64, argmax [A] int32) (tsod_anchor_targets_f32)."""
+    require_cuda(anchor, "anchor_targets")
+    anchor, bbox = anchor.contiguous(), bbox.to(anchor.device, torch.float32).contiguous()
+    A, G = anchor.shape[0], bbox.shape[0]
+    dev = anchor.device
+    loc = torch.empty((A, 4), dtype=torch.float32, device=dev)
+    label = torch.empty((A,), dtype=torch.int64, device=dev)
+    argmax = torch.empty((A,), dtype=torch.int32, device=dev)
+    ws_bytes = lib().tsod_anchor_targets_workspace_bytes(A, G)
+    ws = ARENA.get(dev, ws_bytes)
+    check(lib().tsod_anchor_targets_f32(ptr(anchor), A, ptr(bbox) if G else None, G, float(pos_iou_thresh),
+                                        float(neg_iou_thresh), int(n_pos), int(n_sample), ptr(loc), ptr(label), ptr(argmax),
+                                        ptr(ws), ws_bytes, stream_ptr()), "anchor_targets")
+    return loc, label, argmax
+
+
+def proposal_targets(roi: torch.Tensor, bbox: torch.Tensor, label: torch.Tensor, n_sample: int, pos_per_image: int,
+                     pos_iou_thresh: float, neg_iou_thresh_high: float, neg_iou_thresh_low: float):
+    """roi [R,4], bbox [G,4], label [G] int64 -> (sample_roi [n_sample,4], gt_roi_loc [n_sample,4], gt_roi_label [n_sample]
+    int64, counts [4] int32 = (rows kept, positives, negatives, status)) (tsod_proposal_targets_f32)."""
+    require_cuda(roi, "proposal_targets")
+    dev = roi.device
+    roi, bbox = roi.contiguous(), bbox.to(dev, torch.float32).contiguous()
+    label = label.to(dev, torch.int64).contiguous()
+    R, G = roi.shape[0], bbox.shape[0]
+    sample_roi = torch.empty((n_sample, 4), dtype=torch.float32, device=dev)
+    gt_roi_loc = torch.empty((n_sample, 4), dtype=torch.float32, device=dev)
+    gt_roi_label = torch.empty((n_sample,), dtype=torch.int64, device=dev)
+    counts = torch.empty((4,), dtype=torch.int32, device=dev)
+    ws_bytes = lib().tsod_proposal_targets_workspace_bytes(R, G, n_sample)
+    ws = ARENA.get(dev, ws_bytes)
+    check(lib().tsod_proposal_targets_f32(ptr(roi) if R else None, R, ptr(bbox) if G else None, G, ptr(label) if G else None,
+                                          int(n_sample), int(pos_per_image), float(pos_iou_thresh), float(neg_iou_thresh_high),
+                                          float(neg_iou_thresh_low), ptr(sample_roi), ptr(gt_roi_loc), ptr(gt_roi_label),
+                                          ptr(counts), ptr(ws), ws_bytes, stream_ptr()), "proposal_targets")
+    return sample_roi, gt_roi_loc, gt_roi_label, counts
+
+
 # ----------------------------------------------------------------------------- input step
 _RESIZE_TABLES: dict = {}
 
