@@ -99,7 +99,11 @@ int tsod_pack_conv_weight_f32(const float *w_oihw, int32_t Cout, int32_t Cin_src
                               int32_t Cin, int32_t KW, float *w_packed, tsod_stream_t stream);
 
 /* Bytes of workspace tsod_conv2d_f32 needs for this descriptor (0 unless some tile is K-sliced).
- * Workspace contract: 16-byte aligned, private to one stream at a time. */
+ * Workspace contract: 16-byte aligned, private to one stream at a time, layout [one int32 arrival ticket per K-sliced
+ * tile, padded to 256 bytes | partial-sum slabs].  K-slices are combined INSIDE the launch: every slice stores its slab
+ * write-through, the slice that arrives last at the tile's ticket sums the slabs in slice order (bit-reproducible) and
+ * applies the epilogue.  The tickets must be ZERO when a launch starts; every launch leaves them zero, so zero-fill the
+ * buffer once when it is allocated and never lend it to another kernel in between. */
 size_t tsod_conv2d_workspace_bytes(const tsod_conv2d_desc *d);
 /* Resolve TSOD_TILE_AUTO / split_k == 0 to the concrete choice the heuristic makes. */
 int tsod_conv2d_resolve(const tsod_conv2d_desc *d, int32_t *tile, int32_t *split_k);

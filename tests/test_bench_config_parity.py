@@ -38,16 +38,24 @@ def r50():
 
 
 def _tile_tables():
-    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_autotuned_tiles_b1*.json")))
+    """(file, key) of every committed table: round-1 files hold one list, later ones bench.py's
+    {"serial": [...], "in_flight": [...]} pair."""
+    out = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_autotuned_tiles_b1*.json"))):
+        d = json.load(open(f))
+        out += [(f, None)] if isinstance(d, list) else [(f, k) for k in sorted(d)]
+    return out
 
 
-@pytest.mark.parametrize("table", _tile_tables(), ids=os.path.basename)
+@pytest.mark.parametrize("table", _tile_tables(), ids=lambda t: os.path.basename(t[0]) + (":" + t[1] if t[1] else ""))
 def test_detector_with_the_committed_autotuned_tile_tables(dev, r50, table):
     """bench.py pins (tile, split_k) per layer from Plan.autotune(); the committed tables hold tiles 3..15 and
     K-slice counts -1, 1, 3, 4, 6, 8, 12.  Same forward, those choices imported: same RoIs position for position."""
     from two_stage_object_detection_amd.testing import compare_detector_outputs
     model, sd, x, ref = r50
+    table, key = table
     tiles = json.load(open(table))
+    tiles = tiles if key is None else tiles[key]
     xg = x.to(dev)
     with torch.inference_mode():
         model(xg)

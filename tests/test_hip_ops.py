@@ -89,10 +89,11 @@ def test_conv_matches_cpu(ops, dev, case, tile):
 
 
 def test_conv_kslice_reduce_is_deterministic_under_load(ops, dev):
-    """K-sliced tiles: partial slabs written by the slice workgroups, summed in slice order by
-    conv_reduce_kernel.  Hundreds of back-to-back launches of several slice configurations, each compared
-    word for word with its first result (fixed summation order => bit-reproducible) and against the CPU.
-    Slabs are re-used across launches, so a stale (previous-launch) read would show up as a mismatch."""
+    """K-sliced tiles: partial slabs stored write-through by the slice workgroups, summed in slice order by the slice
+    that arrives last at the tile's ticket (in-launch combine across XCDs).  Hundreds of back-to-back launches of several
+    slice configurations, each compared word for word with its first result (fixed summation order => bit-reproducible)
+    and against the CPU.  Slabs and tickets are re-used across launches, so a stale (previous-launch) slab line read
+    through some L2 / L1, or a ticket not left at zero, would show up as a mismatch."""
     g = torch.Generator().manual_seed(21)
     for (H, W, Cin, Cout, k) in ((25, 42, 512, 512, 3), (50, 84, 256, 256, 3), (13, 17, 1024, 96, 1)):
         x = torch.randn(1, Cin, H, W, generator=g)

@@ -39,6 +39,8 @@ constexpr int kPatchLD = 36;  // row pitch (floats) of the epilogue transpose pa
 struct ConvParams {
     const float *in, *w, *scale, *shift, *res;
     float *out, *partial;
+    int *tickets;                 // one arrival counter per K-sliced tile (zero on entry, left zero on exit)
+    unsigned part_bytes;          // extent of the slab area (buffer descriptor)
     int N, H, W, in_pitch;
     int n_seg, seg_off[TSOD_MAX_SEGMENTS], seg_end[TSOD_MAX_SEGMENTS];  // seg_end = cumulative channel count
     int Cin, Cout, out_pitch, out_off;
@@ -62,6 +64,12 @@ constexpr unsigned kOOB = 0xFFFFFFF0u;  // byte offset beyond any descriptor ext
 
 __device__ __forceinline__ float4 buffer_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+template <int AUX>
+__device__ __forceinline__ float4 buffer_load4_aux(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, AUX);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
@@ -309,16 +317,92 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     const int col_in = lane & 31;
     const int row_in = 4 * (lane >> 5);
     if (z >= 0) {
-        // K-slice: the whole BM x BN partial tile (zero rows / columns included) goes to its own slab
-        float *slab = p.partial + ((long)(tile_id - p.dp_tiles) * p.split + z) * (BM * BN);
+        // K-slice: the whole BM x BN partial tile (zero rows / columns included) goes to this slice's own slab, then the
+        // slice that arrives LAST at the tile's ticket sums the slabs in slice order (fixed order -> bit-reproducible) and
+        // applies the epilogue: no second kernel, no launch boundary.  Hand-off between workgroups that may sit on different
+        // XCDs (private L2s): slabs are stored WRITE-THROUGH (sc1, 16 bytes per lane: each accumulator block goes through the
+        // wave's LDS patch so that a lane owns 4 consecutive columns), every storing wave drains its stores, one lane adds
+        // to the ticket at agent scope, and the reducer reads EVERY slab byte with sc1 loads (never through a stale L1/L2 line).
+        constexpr int AUX_SC1 = 16;
+        const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc((void *)p.partial, (short)0, (int)p.part_bytes, 0x00020000);
+        const int rem = tile_id - p.dp_tiles;
+        const unsigned slab0 = (unsigned)rem * (unsigned)p.split * (unsigned)(BM * BN * 4);   // byte offset of slice 0's slab
+        const unsigned my_slab = slab0 + (unsigned)z * (unsigned)(BM * BN * 4);
+        {
+            float *patch = smem + wave * (32 * kPatchLD);
+            const int pr = lane >> 3, pc = (lane & 7) * 4;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int cl = wn * WN + j * 32 + col_in;
+            for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int rl = wm * WM + i * 32 + row_in;
+                for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) slab[(rl + (e & 3) + 8 * (e >> 2)) * BN + cl] = acc[i][j][e];
+                    for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + row_in) * kPatchLD + col_in] = acc[i][j][e];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float4 v = *reinterpret_cast<const float4 *>(patch + (pr + 8 * t) * kPatchLD + pc);
+                        const int rl = wm * WM + i * 32 + pr + 8 * t, cl = wn * WN + j * 32 + pc;
+                        u32x4 o;
+                        o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_part, my_slab + (unsigned)(rl * BN + cl) * 4u, 0, AUX_SC1);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next block overwrites it
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // EVERY storing wave drains its write-through stores
+        __syncthreads();
+        int *s_flag = reinterpret_cast<int *>(smem);                       // the one LDS array (patches are idle past the barrier)
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(p.tickets + rem, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == p.split - 1;
+            if (last) __hip_atomic_store(p.tickets + rem, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every slice has arrived
+            s_flag[0] = last;
+        }
+        __syncthreads();
+        if (s_flag[0] == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");             // no instruction: keeps the slab loads below the ticket
+        const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, (short)0, (int)p.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), (short)0,
+                                                                               (int)(p.res ? p.res_bytes : 0u), 0x00020000);
+        constexpr int QPR = BN / 4, QUADS = BM * BN / 4;
+        for (int q = tid; q < QUADS; q += THREADS) {
+            const unsigned qoff = slab0 + (unsigned)q * 16u;
+            float4 v = buffer_load4_aux<AUX_SC1>(rs_part, qoff);
+            int sl = 1;
+            for (; sl + 4 <= p.split; sl += 4) {                           // 4 slab loads in flight, added in slice order
+                float4 t4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t4[u] = buffer_load4_aux<AUX_SC1>(rs_part, qoff + (unsigned)(sl + u) * (unsigned)(BM * BN * 4));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v.x += t4[u].x; v.y += t4[u].y; v.z += t4[u].z; v.w += t4[u].w; }
+            }
+            for (; sl < p.split; ++sl) {
+                const float4 t1 = buffer_load4_aux<AUX_SC1>(rs_part, qoff + (unsigned)sl * (unsigned)(BM * BN * 4));
+                v.x += t1.x; v.y += t1.y; v.z += t1.z; v.w += t1.w;
+            }
+            const int m = m0 + q / QPR, n = n0 + (q % QPR) * 4;
+            if (m >= p.M || n >= p.Cout) continue;
+            float vv[4] = {v.x, v.y, v.z, v.w};
+            if (p.vec_epilogue) {                                          // Cout % 4 == 0: all four channels exist
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + n);
+                if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + n);
+                const float4 rs4 = buffer_load4(rs_r, p.res ? ((unsigned)m * (unsigned)p.res_pitch + (unsigned)(p.res_off + n)) * 4u : kOOB);
+                u32x4 o;
+                o.x = __float_as_uint(apply_act(vv[0] * sc.x + sh.x + rs4.x, p.neg_slope, p.act_hi));
+                o.y = __float_as_uint(apply_act(vv[1] * sc.y + sh.y + rs4.y, p.neg_slope, p.act_hi));
+                o.z = __float_as_uint(apply_act(vv[2] * sc.z + sh.z + rs4.z, p.neg_slope, p.act_hi));
+                o.w = __float_as_uint(apply_act(vv[3] * sc.w + sh.w + rs4.w, p.neg_slope, p.act_hi));
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u, 0, 0);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (n + c >= p.Cout) continue;
+                    float o = vv[c] * (p.scale ? p.scale[n + c] : 1.f) + (p.shift ? p.shift[n + c] : 0.f);
+                    if (p.res) o += p.res[(long)m * p.res_pitch + p.res_off + n + c];
+                    p.out[(long)m * p.out_pitch + p.out_off + n + c] = apply_act(o, p.neg_slope, p.act_hi);
+                }
             }
         }
         return;
@@ -405,59 +489,6 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     }
 }
 
-// Deterministic K-slice tail: every thread owns one float4 (4 consecutive output channels of one pixel) of one
-// sliced tile, sums its `split` partial values in slice order (fixed order -> bit-reproducible; the loads of a
-// batch of 8 slices are all in flight before the first add) and applies the epilogue.
-__global__ void __launch_bounds__(256) conv_reduce_kernel(const ConvParams p, int BM, int BN, int rem_tiles) {
-    const int quads = BM * BN / 4, qpr = BN / 4;
-    const long total = (long)rem_tiles * quads;
-    const bool vec_ok = ((p.out_pitch | p.out_off) & 3) == 0 && (!p.res || ((p.res_pitch | p.res_off) & 3) == 0);
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int rt = (int)(t / quads);
-        const int idx = (int)(t - (long)rt * quads);
-        const float4 *slabs = reinterpret_cast<const float4 *>(p.partial) + (long)rt * p.split * quads + idx;
-        float4 v = slabs[0];
-        int s = 1;
-        for (; s + 8 <= p.split; s += 8) {
-            float4 q[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) q[u] = slabs[(long)(s + u) * quads];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { v.x += q[u].x; v.y += q[u].y; v.z += q[u].z; v.w += q[u].w; }
-        }
-        for (; s < p.split; ++s) {
-            const float4 q = slabs[(long)s * quads];
-            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-        }
-        const int tile_id = p.dp_tiles + rt;
-        const int m = (tile_id / p.tiles_n) * BM + idx / qpr;
-        const int nb = (tile_id % p.tiles_n) * BN + (idx % qpr) * 4;
-        if (m >= p.M || nb >= p.Cout) continue;
-        float vv[4] = {v.x, v.y, v.z, v.w};
-        if (nb + 3 < p.Cout && vec_ok) {
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f), rs = sh;
-            if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + nb);
-            if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + nb);
-            if (p.res) rs = *reinterpret_cast<const float4 *>(p.res + (long)m * p.res_pitch + p.res_off + nb);
-            float4 o;
-            o.x = apply_act(vv[0] * sc.x + sh.x + rs.x, p.neg_slope, p.act_hi);
-            o.y = apply_act(vv[1] * sc.y + sh.y + rs.y, p.neg_slope, p.act_hi);
-            o.z = apply_act(vv[2] * sc.z + sh.z + rs.z, p.neg_slope, p.act_hi);
-            o.w = apply_act(vv[3] * sc.w + sh.w + rs.w, p.neg_slope, p.act_hi);
-            *reinterpret_cast<float4 *>(p.out + (long)m * p.out_pitch + p.out_off + nb) = o;
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int n = nb + c;
-                if (n >= p.Cout) continue;
-                float o = vv[c] * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
-                if (p.res) o += p.res[(long)m * p.res_pitch + p.res_off + n];
-                p.out[(long)m * p.out_pitch + p.out_off + n] = apply_act(o, p.neg_slope, p.act_hi);
-            }
-        }
-    }
-}
-
 // torch [Cout][Cin_src][KH][KW_src] -> [Cout][KH][KW][Cin], zero-filling the added channels / taps
 __global__ void __launch_bounds__(256)
 pack_weight_kernel(const float *__restrict__ w, int Cout, int Cin_src, int KH, int KW_src, int Cin, int KW,
@@ -529,9 +560,11 @@ int cu_count() {
 // Workgroups that fit on one CU at a time (LDS-bound: 2 stages of (BM+BN) x 36 floats out of 160 KiB).
 int residency(int tile) { return kTiles[tile].resident; }
 
+constexpr size_t kTicketBytes = 256 * 1024;   // tickets for up to 65536 K-sliced tiles per launch
+
 struct Sched {
     int tile, bm, bn, tiles_m, tiles_n, tiles, dp_tiles, rem_tiles, split, ksteps_per_split, grid;
-    size_t ws_bytes;
+    size_t ws_bytes, ticket_bytes;
     double cost;
 };
 
@@ -564,10 +597,17 @@ Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
     }
     int kps = (ksteps + split - 1) / split;
     split = (ksteps + kps - 1) / kps;                         // no empty slices
-    if (split <= 1) { split = 1; dp = s.tiles; kps = ksteps; }
+    if (split <= 1 || (size_t)(s.tiles - dp) * sizeof(int) > kTicketBytes) {   // (more K-sliced tiles than tickets: whole tiles)
+        split = 1; dp = s.tiles; kps = ksteps;
+    }
     s.split = split; s.ksteps_per_split = kps; s.dp_tiles = dp; s.rem_tiles = s.tiles - dp;
     s.grid = dp + s.rem_tiles * split;
-    s.ws_bytes = (size_t)s.rem_tiles * split * s.bm * s.bn * sizeof(float);
+    // workspace = [kTicketBytes of arrival tickets, one int per K-sliced tile][rem_tiles * split slabs of BM x BN floats].
+    // The ticket area has ONE size for every launch: launches that share a workspace must never see another launch's
+    // slab bytes where they expect zeroed tickets.
+    s.ticket_bytes = s.rem_tiles > 0 ? kTicketBytes : 0;
+    s.ws_bytes = s.ticket_bytes + (size_t)s.rem_tiles * split * s.bm * s.bn * sizeof(float);
+
     // cost, in cycles of the most loaded CU: co-resident workgroups share the CU's matrix pipes, so a wave of
     // workgroups costs (workgroups per CU) x (K-steps x BM*BN/4 MFMA cycles + fixed prologue/epilogue)
     const double step = (double)s.bm * s.bn / 4.0 * kTiles[tile].cost * (bk / 32);
@@ -575,8 +615,8 @@ Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
     const int cus = cu_count();
     double c = (double)tsod_cdiv(dp, cus) * (ksteps * step + fixed);
     if (s.rem_tiles > 0)
-        c += (double)tsod_cdiv((int64_t)s.rem_tiles * split, cus) * (kps * step + fixed) + 5000.0 +
-             (double)s.rem_tiles * (split + 1) * s.bm * s.bn * 4.0 / 2000.0;
+        c += (double)tsod_cdiv((int64_t)s.rem_tiles * split, cus) * (kps * step + fixed) + 2500.0 +
+             (double)split * s.bm * s.bn * 4.0 / 60.0;     // last arriver: serial read of `split` slabs at ~60 B/cycle
     s.cost = c;
     return s;
 }
@@ -635,7 +675,6 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
 
     ConvParams p;
     p.in = in; p.w = w_packed; p.scale = scale; p.shift = shift; p.res = residual; p.out = out;
-    p.partial = static_cast<float *>(workspace);
     p.N = d->N; p.H = d->H; p.W = d->W; p.in_pitch = d->in_pitch;
     p.n_seg = d->n_seg;
     int cum = 0;
@@ -675,7 +714,12 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
     p.ksteps = (p.K + kTiles[sc.tile].bk - 1) / kTiles[sc.tile].bk;
     p.tiles_m = sc.tiles_m; p.tiles_n = sc.tiles_n;
     p.dp_tiles = sc.dp_tiles; p.split = sc.split; p.ksteps_per_split = sc.ksteps_per_split;
-    if (sc.rem_tiles > 0) TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= sc.ws_bytes, TSOD_ERR_WORKSPACE);
+    if (sc.rem_tiles > 0)
+        TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= sc.ws_bytes && tsod_aligned16(workspace), TSOD_ERR_WORKSPACE);
+    p.tickets = static_cast<int *>(workspace);
+    p.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + sc.ticket_bytes);
+    p.part_bytes = (unsigned)(sc.ws_bytes - sc.ticket_bytes);
+    TSOD_REQUIRE(sc.ws_bytes < 0xFFFFFFF0ull, TSOD_ERR_UNSUPPORTED);
     hipStream_t s = tsod_stream(stream);
     switch (sc.tile) {
         case TSOD_TILE_128x128: launch_tile<128, 128, 64, 64, 2>(p, sc.grid, s); break;
@@ -693,12 +737,6 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
         case TSOD_TILE_128x64_S1: launch_tile<128, 64, 64, 32, 4, 1>(p, sc.grid, s); break;
         case TSOD_TILE_64x128_S1: launch_tile<64, 128, 32, 64, 4, 1>(p, sc.grid, s); break;
         default: launch_tile<64, 64, 32, 32, 4>(p, sc.grid, s); break;
-    }
-    if (sc.rem_tiles > 0)
-    {
-        const long quads = (long)sc.rem_tiles * sc.bm * sc.bn / 4;
-        const int blocks = (int)(tsod_cdiv(quads, 256) < 4096 ? tsod_cdiv(quads, 256) : 4096);
-        hipLaunchKernelGGL(conv_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, sc.bm, sc.bn, sc.rem_tiles);
     }
     return tsod_launch_status();
 }

@@ -167,7 +167,8 @@ class Plan:
         return out
 
     def finalize(self):
-        """Size the shared split-K workspace (stream order makes sharing safe) and bind it."""
+        """Size the shared K-slice workspace (stream order makes sharing safe) and bind it.  Its head holds the arrival
+        tickets of the K-sliced tiles, which every launch expects to find zero and leaves zero: zero-filled once here."""
         need = 256
         for st in self.conv_steps:
             st.ws_bytes = lib().tsod_conv2d_workspace_bytes(byref(st.desc))
@@ -176,7 +177,7 @@ class Plan:
             if self.workspace is not None:
                 # a HIP graph captured from this plan earlier has the old pointer baked in: the buffer must outlive it
                 self._retired.append(self.workspace)
-            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
         for st in self.conv_steps:
             st.args[7] = ptr(self.workspace)
             st.args[8] = self.workspace.numel()
@@ -220,7 +221,7 @@ class Plan:
         schedule that fills the whole chip for one launch is not automatically the cheapest."""
         self.graph = None
         concurrent = max(1, int(concurrent))
-        bigs = [torch.empty(512 << 20, dtype=torch.uint8, device=self.device) for _ in range(concurrent)]
+        bigs = [torch.zeros(512 << 20, dtype=torch.uint8, device=self.device) for _ in range(concurrent)]   # zero tickets
         big = bigs[0]
         side = [torch.cuda.Stream(self.device) for _ in range(concurrent - 1)]
         results = []

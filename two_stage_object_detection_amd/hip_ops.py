@@ -27,22 +27,14 @@ class _Arena:
     A buffer that has been handed out is never freed or replaced under a HIP graph that may have its pointer baked in:
     outgrown buffers are retired, not released (``release(owner)`` drops an owner's buffers explicitly)."""
 
-    def __init__(self):
+    def __init__(self, zero: bool = False):
         self._buf = {}
         self._retired = {}
         self._tls = threading.local()
-
-    @contextlib.contextmanager
-    def scope(self, owner):
-        prev = getattr(self._tls, "owner", None)
-        self._tls.owner = owner
-        try:
-            yield
-        finally:
-            self._tls.owner = prev
+        self._zero = zero            # conv workspaces start with arrival tickets that must be zero when first used
 
     def _key(self, device):
-        owner = getattr(self._tls, "owner", None)
+        owner = getattr(_OWNER_TLS, "owner", None)
         if owner is not None:
             return (device, "owner", owner)
         return (device, "stream", torch.cuda.current_stream(device).cuda_stream)
@@ -54,7 +46,8 @@ class _Arena:
         if cur is None or cur.numel() < nbytes:
             if cur is not None:
                 self._retired.setdefault(key, []).append(cur)
-            cur = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+            alloc = torch.zeros if self._zero else torch.empty
+            cur = alloc(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
             self._buf[key] = cur
         return cur
 
@@ -64,8 +57,28 @@ class _Arena:
             self._buf.pop(key, None)
             self._retired.pop(key, None)
 
+    def scope(self, owner):                                   # both arenas share one owner scope
+        return _owner_scope(owner)
+
+
+_OWNER_TLS = threading.local()
+
+
+@contextlib.contextmanager
+def _owner_scope(owner):
+    prev = getattr(_OWNER_TLS, "owner", None)
+    _OWNER_TLS.owner = owner
+    try:
+        yield
+    finally:
+        _OWNER_TLS.owner = prev
+
 
 ARENA = _Arena()
+# K-sliced GEMM workspaces (tsod_conv2d_f32 / tsod_linear_f32): [arrival tickets | partial slabs].  The tickets must be
+# zero when a launch starts and every launch leaves them zero, so these buffers are zero-filled once at allocation and
+# never lent to any other kernel (the NMS masks live in ARENA).
+CONV_ARENA = _Arena(zero=True)
 
 
 # ----------------------------------------------------------------------------- layout
@@ -126,7 +139,7 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
                        KH=KH, KW=KW, stride=stride, pad_h=pad, pad_w=pad, OH=OH, OW=OW, act=act, slope=slope,
                        res_pitch=0 if residual is None else residual.shape[-1], res_off=0, tile=tile, split_k=split_k)
     ws_bytes = lib().tsod_conv2d_workspace_bytes(byref(d))
-    ws = ARENA.get(x.device, ws_bytes) if ws_bytes else None
+    ws = CONV_ARENA.get(x.device, ws_bytes) if ws_bytes else None
     check(lib().tsod_conv2d_f32(byref(d), ptr(x), ptr(w_packed), ptr(scale), ptr(shift), ptr(residual), ptr(out),
                                 ptr(ws), ws_bytes, stream_ptr()), "conv2d")
     return out
@@ -147,7 +160,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = No
     N = weight.shape[0]
     out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     ws_bytes = lib().tsod_linear_workspace_bytes(M, K, N)
-    ws = ARENA.get(x.device, ws_bytes) if ws_bytes else None
+    ws = CONV_ARENA.get(x.device, ws_bytes) if ws_bytes else None
     check(lib().tsod_linear_f32(ptr(x), M, K, K, ptr(weight), ptr(bias), N, ptr(out), N, ptr(ws), ws_bytes,
                                 stream_ptr()), "linear")
     return out
