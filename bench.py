@@ -67,6 +67,9 @@ def parse(argv=None):
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--num-classes", type=int, default=80)
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--precision", default="auto", choices=("f32", "bf16x3", "auto"), help="arithmetic of the conv GEMMs: f32 = "
+                    "v_mfma_f32_32x32x2_f32; bf16x3 = three exact bf16 pieces per operand on v_mfma_f32_32x32x16_bf16 "
+                    "(f32-accurate, gated by the same parity suite); auto = the autotuner picks per layer")
     ap.add_argument("--autotune-splits", default=None, help="comma list restricting the K-slice candidates of the autotuner")
     ap.add_argument("--in-flight", type=int, default=4, help="steps in flight: consecutive steps are issued round-robin on this "
                     "many HIP streams, each with its own graph and buffers (request-level pipelining of a batch-1 server)")
@@ -337,6 +340,8 @@ def main(argv=None):
 
     model, sd = synthetic_detector(args.backbone, num_classes=args.num_classes, seed=0)
     model = model.to(dev).eval()
+    if args.precision == "bf16x3":
+        model.extractor.set_conv_precision("bf16x3")
 
     def images(r):
         return torch.rand(B, 3, args.height, args.width, generator=torch.Generator().manual_seed(1234 + r))
@@ -355,10 +360,11 @@ def main(argv=None):
             tiles = json.load(open(args.tiles_file))
         elif not args.no_autotune:
             splits = [int(v) for v in args.autotune_splits.split(",")] if args.autotune_splits else None
-            plan.autotune(verbose=args.verbose and rank == 0, splits=splits, concurrent=1)
+            precs = {"f32": (0,), "bf16x3": (1,), "auto": (0, 1)}[args.precision]
+            plan.autotune(verbose=args.verbose and rank == 0, splits=splits, concurrent=1, precisions=precs)
             tiles["serial"] = plan.export_tiles()
             if n_fly > 1:                                              # objective of an overlapped server: two copies in flight
-                plan.autotune(verbose=False, splits=splits, concurrent=2)
+                plan.autotune(verbose=False, splits=splits, concurrent=2, precisions=precs)
                 tiles["in_flight"] = plan.export_tiles()
             else:
                 tiles["in_flight"] = tiles["serial"]

@@ -66,6 +66,15 @@ enum { TSOD_TILE_AUTO = 0, TSOD_TILE_128x128 = 1, TSOD_TILE_128x64 = 2, TSOD_TIL
        TSOD_TILE_128x64_W8_S1 = 9, TSOD_TILE_64x64_S1_K64 = 10, TSOD_TILE_128x64_W8_S1_K64 = 11,
        TSOD_TILE_64x64_W1_S1 = 12, TSOD_TILE_128x64_W2_S1 = 13, TSOD_TILE_128x64_S1 = 14, TSOD_TILE_64x128_S1 = 15,
        TSOD_TILE_COUNT = 16 };
+/* arithmetic of the contraction.  F32: v_mfma_f32_32x32x2_f32 (a k-ordered f32 fma chain).  BF16X3: every f32 operand cut
+ * exactly into three bf16 pieces (hi + mid + lo == x), six piece products per k accumulated in f32 on
+ * v_mfma_f32_32x32x16_bf16: f32-level accuracy (error ~1.3e-7 of sum|a*b|) at 0.375x the matrix-pipe time; storage,
+ * accumulation and epilogue are f32 either way.  Tiles available in BF16X3: 64x64, 64x64_S1, 128x64_W8_S1, 64x64_S1_K64,
+ * 128x64_S1, 64x128_S1 (TSOD_ERR_UNSUPPORTED for the others). */
+enum { TSOD_PREC_F32 = 0, TSOD_PREC_BF16X3 = 1 };
+/* With TSOD_PREC_BF16X3 the `w_packed` argument of tsod_conv2d_f32 is the PRE-SPLIT weight image made once by
+ * tsod_pack_conv_weight_bf16x3 from the f32 packed weights [Cout][K]: [Cout][ceil(K/8)][hi | mid | lo][8] bf16, 48 bytes per
+ * 8 k (tsod_conv_weight_bf16x3_bytes), every weight cut exactly (hi + mid + lo == w).  Activations are split on the fly. */
 #define TSOD_MAX_SEGMENTS 16
 
 typedef struct tsod_conv2d_desc {
@@ -89,6 +98,7 @@ typedef struct tsod_conv2d_desc {
     int32_t split_k;       /* 1 = whole tiles only; S > 1 = every tile cut into S K-slices; -1 = hybrid (full
                               chip-waves of whole tiles, left-over tiles K-sliced to fill the last wave);
                               0 = built-in cost model chooses */
+    int32_t precision;     /* TSOD_PREC_* (0 = F32) */
 } tsod_conv2d_desc;
 
 /* Packed weight layout Wp: [Cout][KH][KW][Cin] f32 (k = (kh*KW + kw)*Cin + ci, ci running over
@@ -97,6 +107,10 @@ typedef struct tsod_conv2d_desc {
  * stems); KW >= KW_src, extra taps on the right get zero weights (the 7x7 stem runs as 7x8). */
 int tsod_pack_conv_weight_f32(const float *w_oihw, int32_t Cout, int32_t Cin_src, int32_t KH, int32_t KW_src,
                               int32_t Cin, int32_t KW, float *w_packed, tsod_stream_t stream);
+
+size_t tsod_conv_weight_bf16x3_bytes(int32_t Cout, int32_t K);
+int tsod_pack_conv_weight_bf16x3(const float *w_packed /* [Cout][K] f32 */, int32_t Cout, int32_t K, void *w_bf16x3,
+                                 tsod_stream_t stream);
 
 /* Bytes of workspace tsod_conv2d_f32 needs for this descriptor (0 unless some tile is K-sliced).
  * Workspace contract: 16-byte aligned, private to one stream at a time, layout [one int32 arrival ticket per K-sliced

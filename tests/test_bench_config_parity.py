@@ -17,6 +17,7 @@ import pytest
 import torch
 
 import oracle
+import oracle.detector
 
 pytestmark = pytest.mark.gpu
 
@@ -62,12 +63,12 @@ def test_detector_with_the_committed_autotuned_tile_tables(dev, r50, table):
         plan = model.extractor._plan_for(xg)
         before = plan.export_tiles()
         plan.import_tiles(tiles)
-        assert plan.export_tiles() == [tuple(t) for t in tiles]
+        assert plan.export_tiles() == [tuple(t) + ((0,) if len(t) == 3 else ()) for t in tiles]
         got = [o.cpu() for o in model(xg)]
         model.raise_if_error()
         plan.import_tiles(before)                                # leave the shared model as the other tests expect it
     rep = compare_detector_outputs(got, ref)
-    print(os.path.basename(table), sorted({(t, s) for _, t, s in tiles}), rep)
+    print(os.path.basename(table), sorted({tuple(r[1:]) for r in tiles}), rep)
     assert rep["ok"], rep
     assert rep["rows_positional_mismatch"] == 0 and rep["rows_unmatched"] == 0 and rep["class_mismatch"] == 0, rep
 
@@ -84,14 +85,14 @@ def test_detector_after_plan_autotune_and_through_the_serving_path(dev, r50):
         model(xg)
         plan = model.extractor._plan_for(xg)
         before = plan.export_tiles()
-        res = plan.autotune(reps=2, concurrent=2)
+        res = plan.autotune(reps=2, concurrent=2, precisions=(0, 1))     # bench.py --precision auto: f32 and bf16x3 compete
         tuned = plan.export_tiles()
         assert len(res) == len(plan.conv_steps) == 53
-        assert all(t in range(1, 16) for _, t, _ in tuned)
+        assert all(t in range(1, 16) and p in (0, 1) for _, t, _, p in tuned)
         got = [o.cpu() for o in model(xg)]
         model.raise_if_error()
         rep = compare_detector_outputs(got, ref)
-        print("autotuned eager", sorted({(t, s) for _, t, s in tuned}), rep)
+        print("autotuned eager", sorted({tuple(r[1:]) for r in tuned}), rep)
         assert rep["ok"] and rep["rows_positional_mismatch"] == 0 and rep["rows_unmatched"] == 0, rep
         server = InFlightDetector(model, xg, depth=4, tiles=tuned)
         tickets = [server.submit(xg) for _ in range(8)]
@@ -104,6 +105,34 @@ def test_detector_after_plan_autotune_and_through_the_serving_path(dev, r50):
             assert (outs[4][..., :5] - det_ref[..., :5]).abs().max().item() <= 1e-3
         server.drain()
         plan.import_tiles(before)
+
+
+@pytest.mark.parametrize("backbone,shape", [("resnet50", (1, 3, 800, 1333)), ("resnet50", (2, 3, 320, 448)), ("hardnet39", (2, 3, 320, 448))])
+def test_detector_with_every_dense_conv_in_bf16x3(dev, backbone, shape):
+    """SURVEY 8(f) rank 4, second half: the reduced-precision (bf16x3) conv path, gated by the SAME parity suite: the
+    whole trunk on three-piece bf16 MFMAs must give the oracle's RoIs / scores / classes to the bars of the f32 path."""
+    from two_stage_object_detection_amd.testing import compare_detector_outputs, synthetic_detector
+    model, sd = synthetic_detector(backbone, num_classes=20, seed=0)
+    if backbone.startswith("hardnet"):
+        oracle.calibrate_bn(sd, _img((2, 3, 256, 320), seed=99), oracle.hardnet_trunk, arch=int(backbone[-2:]), prefix="extractor.")
+        model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    model.extractor.set_conv_precision("bf16x3")
+    x = _img(shape)
+    with torch.inference_mode():
+        ref = oracle.detector_forward(sd, x, backbone=backbone)
+        got = [o.cpu() for o in model(x.to(dev))]
+        model.raise_if_error()
+        plan = model.extractor._plan_for(x.to(dev))
+        assert all(p == 1 for _, _, _, p in plan.export_tiles())
+        feat_ref = oracle.detector.extractor_forward(sd, x, backbone)
+        feat = model(x.to(dev), mode="extractor").cpu()
+    scale = float(feat_ref.abs().max())
+    assert float((feat - feat_ref).abs().max()) <= (2e-5 if backbone == "resnet50" else 5e-5) * scale + 1e-6     # the f32 path's feature bar
+    rep = compare_detector_outputs(got, ref)
+    print("bf16x3", backbone, shape, rep)
+    assert rep["ok"] and rep["rows_unmatched"] == 0 and rep["class_mismatch"] == 0, rep
+    assert rep["rows_positional_mismatch"] <= 4, rep      # another arithmetic rounds differently: a near-tie may swap two rows
 
 
 def test_config4_hardnet68_batch8_full_size(dev):

@@ -512,7 +512,7 @@ def test_retuning_a_plan_keeps_earlier_graphs_valid(dev, synth):
         run, _, outs = model.make_graphed(x, slot=5)
         plan = model.extractor._plan_for(x, 5)
         ws_before = plan.workspace
-        plan.import_tiles([(n, 3, 16) for n, _, _ in plan.export_tiles()])     # every layer K-sliced 16x: bigger workspace
+        plan.import_tiles([(r[0], 3, 16) for r in plan.export_tiles()])     # every layer K-sliced 16x: bigger workspace
         assert plan.workspace is not ws_before and any(w is ws_before for w in plan._retired)
         torch.empty(64 << 20, device=dev).fill_(1.0)                           # would land in a freed workspace
         run()

@@ -88,6 +88,46 @@ def test_conv_matches_cpu(ops, dev, case, tile):
         assert (got - ref).abs().max().item() <= tol, (case, tile, split)
 
 
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", [0] + list(__import__("two_stage_object_detection_amd._ffi", fromlist=["BF16X3_TILE_IDS"]).BF16X3_TILE_IDS))
+def test_conv_bf16x3_matches_cpu(ops, dev, case, tile):
+    """desc.precision = TSOD_PREC_BF16X3 (the reduced-precision conv path, gated by parity): every
+    operand cut exactly into three bf16 pieces, six piece products per k on the bf16 matrix pipes, f32 accumulation.
+    Same bar as the f32 MFMA path against the f64 CPU convolution - it has to be f32-accurate to be usable at all - and it
+    must actually be a different arithmetic (not bit-equal to the f32 path on every case)."""
+    N, H, W, Cin, Cout, k, stride, pad = case
+    ref, xn, wp = _conv_case(case, dev, ops)
+    ksteps = (Cin * k * k + 31) // 32
+    tol = 3e-6 * math.sqrt(Cin * k * k) + 1e-5
+    f32 = ops.nhwc_to_nchw(ops.conv2d_nhwc(xn, wp, stride=stride, pad=pad, tile=3, split_k=1)).cpu()
+    for split in [0, 1, -1] + [s for s in (2, 3, 6) if ksteps // s >= 2]:
+        y = ops.conv2d_nhwc(xn, wp, stride=stride, pad=pad, tile=tile, split_k=split, precision=1)
+        got = ops.nhwc_to_nchw(y).cpu()
+        assert (got - ref).abs().max().item() <= tol, (case, tile, split)
+        assert (got - ref).abs().max().item() <= 2.0 * (f32 - ref).abs().max().item() + 1e-6, "not f32-accurate"
+    if Cin * k * k >= 512:
+        assert not torch.equal(got, f32)
+
+
+def test_conv_bf16x3_exact_on_bf16_representable_inputs(ops, dev):
+    """With operands that ARE bf16 values the mid / lo pieces are zero and the six-product sum is the plain product: the
+    bf16x3 path must then agree with the f32 path to accumulation-order noise; with operands carrying all 24 significand
+    bits it must still agree (that is the point of the three pieces) - a single-piece (plain bf16) GEMM would be off by ~1e-2."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 256, 20, 24, generator=g)
+    w = torch.randn(128, 256, 3, 3, generator=g) / 48
+    ref = _conv_ref(x, w, 1, 1)
+    xn, wp = ops.nchw_to_nhwc(x.to(dev)), ops.pack_conv_weight(w.to(dev))
+    got = ops.nhwc_to_nchw(ops.conv2d_nhwc(xn, wp, pad=1, precision=1)).cpu()
+    err = (got - ref).abs().max().item()
+    plain_bf16 = _conv_ref(x.bfloat16().float(), w.bfloat16().float(), 1, 1)
+    assert err < 2e-5 and (plain_bf16 - ref).abs().max().item() > 100 * err
+    # unsupported tile for this precision is refused, not silently run in f32
+    from two_stage_object_detection_amd._ffi import TsodError
+    with pytest.raises(TsodError, match="no kernel|unsupported|UNSUPPORTED"):
+        ops.conv2d_nhwc(xn, wp, pad=1, tile=1, precision=1)
+
+
 def test_conv_kslice_reduce_is_deterministic_under_load(ops, dev):
     """K-sliced tiles: partial slabs stored write-through by the slice workgroups, summed in slice order by the slice
     that arrives last at the tile's ticket (in-launch combine across XCDs).  Hundreds of back-to-back launches of several

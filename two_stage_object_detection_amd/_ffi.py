@@ -20,6 +20,9 @@ TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4
 TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "64x128", 5: "128x128w8", 6: "128x64w8", 7: "256x128w8",
               8: "64x64s1", 9: "128x64w8s1", 10: "64x64s1k64", 11: "128x64w8s1k64", 12: "64x64w1s1", 13: "128x64w2s1", 14: "128x64s1", 15: "64x128s1"}
 TILE_IDS = tuple(range(1, 16))
+PREC_F32, PREC_BF16X3 = 0, 1
+PREC_NAMES = {0: "f32", 1: "bf16x3"}
+BF16X3_TILE_IDS = (3, 8, 9, 10, 14, 15)          # tiles that also exist as bf16x3 variants (include/tsod.h)
 
 
 class TsodError(RuntimeError):
@@ -35,7 +38,7 @@ class ConvDesc(Structure):
         ("Cout", c_int32), ("out_pitch", c_int32), ("out_off", c_int32),
         ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad_h", c_int32), ("pad_w", c_int32),
         ("OH", c_int32), ("OW", c_int32), ("act", c_int32), ("slope", c_float),
-        ("res_pitch", c_int32), ("res_off", c_int32), ("tile", c_int32), ("split_k", c_int32),
+        ("res_pitch", c_int32), ("res_off", c_int32), ("tile", c_int32), ("split_k", c_int32), ("precision", c_int32),
     ]
 
 
@@ -45,6 +48,8 @@ _SIGNATURES = {
     "tsod_version": (c_int, []),
     "tsod_device_cu_count": (c_int, []),
     "tsod_pack_conv_weight_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "tsod_conv_weight_bf16x3_bytes": (c_size_t, [c_int32, c_int32]),
+    "tsod_pack_conv_weight_bf16x3": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "tsod_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "tsod_conv2d_resolve": (c_int, [POINTER(ConvDesc), POINTER(c_int32), POINTER(c_int32)]),
     "tsod_conv2d_f32": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -161,7 +166,8 @@ def require_cuda(t, what: str) -> None:
 
 
 def make_conv_desc(*, N, H, W, in_pitch, segs, Cout, out_pitch, out_off=0, KH=1, KW=1, stride=1, pad_h=0, pad_w=0,
-                   OH=None, OW=None, act=ACT_NONE, slope=0.0, res_pitch=0, res_off=0, tile=TILE_AUTO, split_k=0) -> ConvDesc:
+                   OH=None, OW=None, act=ACT_NONE, slope=0.0, res_pitch=0, res_off=0, tile=TILE_AUTO, split_k=0,
+                   precision=0) -> ConvDesc:
     d = ConvDesc()
     d.N, d.H, d.W, d.in_pitch = N, H, W, in_pitch
     d.n_seg = len(segs)
@@ -173,4 +179,5 @@ def make_conv_desc(*, N, H, W, in_pitch, segs, Cout, out_pitch, out_off=0, KH=1,
     d.OW = OW if OW is not None else (W + 2 * pad_w - KW) // stride + 1
     d.act, d.slope = act, float(slope)
     d.res_pitch, d.res_off, d.tile, d.split_k = res_pitch, res_off, tile, split_k
+    d.precision = int(precision)
     return d

@@ -27,12 +27,20 @@
 //                      split across workgroups (deterministic slab reduction in a second kernel).
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous run of tiles that
 // share activation rows.
+//
+// PREC = 1 ("bf16x3", desc.precision = TSOD_PREC_BF16X3): the same kernel with the f32 operands cut EXACTLY into three
+// bf16 pieces (8 + 8 + 8 significand bits by truncation: hi + mid + lo == x) on their way into LDS, and every product
+// accumulated in f32 from its six largest piece products (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the three dropped
+// ones are <= 2^-24 relative) on v_mfma_f32_32x32x16_bf16 - 16x the f32 MFMA rate, 6 instructions per 16 k instead of
+// 8 per 16 k at 1/16 the rate: 0.375x the matrix-pipe time at f32-level accuracy (error ~1.3e-7 of sum|a*b|, the f32 fma
+// chain's is 1.4-2.5e-7).  Storage, accumulation, epilogue, scheduling and K-slice combine are unchanged.
 #include "tsod_internal.h"
 #include <limits.h>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kPatchLD = 36;  // row pitch (floats) of the epilogue transpose patches
 
@@ -79,6 +87,32 @@ __device__ __forceinline__ float apply_act(float v, float neg_slope, float hi) {
     return fminf(fmaxf(v, 0.f) + neg_slope * fminf(v, 0.f), hi);
 }
 
+// x == hi + mid + lo exactly, each piece a bf16 (kept in the upper half of a 32-bit word): truncation leaves <= 16, then <= 8
+// significant bits, so both subtractions are exact.
+__device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsigned &l) {
+    h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(m);
+    l = __float_as_uint(r2) & 0xFFFF0000u;
+}
+__device__ __forceinline__ unsigned pack2(unsigned lo_elem, unsigned hi_elem) { return (lo_elem >> 16) | hi_elem; }
+
+// Two operands at once on the hardware converter (v_cvt_pk_bf16_f32, round to nearest even): h, m, l = packed bf16 pairs
+// (x0 in the low half = the lower k).  x - bf16(x) is exact (the pieces are within half a bf16 ulp), so h + m + l differs
+// from x by at most the rounding of the LAST piece, <= 2^-26 |x|: below the dropped piece products.  5.5 VALU ops per
+// element instead of 9.5 for the truncating form.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    f32x2 v = {x0, x1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    f32x2 r1 = {x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xFFFF0000u)};
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+    f32x2 r2 = {r1.x - __uint_as_float(m << 16), r1.y - __uint_as_float(m & 0xFFFF0000u)};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+
 // channel index inside the (concatenated) Cin -> offset inside the input pixel (select chain, no branches)
 __device__ __forceinline__ int seg_channel(const ConvParams &p, int ci) {
     int ch = p.seg_off[0] + ci;
@@ -99,16 +133,24 @@ __device__ __forceinline__ int seg_channel(const ConvParams &p, int ci) {
 __device__ long long *g_clock_buf = nullptr;
 #endif
 
-template <int BM, int BN, int WM, int WN, int MIN_WAVES, int NBUF = 2, int BK = 32>
+template <int BM, int BN, int WM, int WN, int MIN_WAVES, int NBUF = 2, int BK = 32, int PREC = 0>
 __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_igemm_kernel(const ConvParams p) {
-    constexpr int kBK = BK, kLDK = BK + 4;
+    // f32: rows of BK + 4 floats.  bf16x3: three planes (hi, mid, lo) per operand, rows of BK bf16 + 16 bytes
+    // (pitch 80 B at BK = 32: the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots), counted in floats here
+    constexpr int kBK = BK, kLDK = PREC ? BK / 2 + 4 : BK + 4;
+    constexpr int kPlanes = PREC ? 3 : 1;
     constexpr int TPR = BK / 4;                        // threads per staged row (16-byte chunks)
     constexpr int WAVES_N = BN / WN;
     constexpr int THREADS = 64 * (BM / WM) * WAVES_N;
     constexpr int RPP = THREADS / TPR;                 // rows staged per pass
     constexpr int TM = WM / 32, TN = WN / 32;          // 32x32 MFMA tiles per wave in m / n
-    constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;  // rows each thread stages per K-step
-    constexpr int STAGE = (BM + BN) * kLDK;
+    constexpr int A_ROWS = BM / RPP;                   // A rows each thread stages per K-step (one float4 chunk each)
+    // B per thread and K-step.  f32: BN / RPP float4 chunks.  bf16x3: the weights arrive PRE-SPLIT, [Cout][K/8][hi|mid|lo][8]
+    // bf16 (48 bytes per 8 k), so a thread moves whole 8-k groups: three 16-byte loads, three ds_write_b128, no VALU.
+    constexpr int GPR = BK / 8;                        // 8-k groups per row and K-step
+    constexpr int B_TASKS = (BN * GPR + THREADS - 1) / THREADS;
+    constexpr int B_ROWS = PREC ? 3 * B_TASKS : BN / RPP;   // staging registers (16 bytes each) for B
+    constexpr int STAGE = kPlanes * (BM + BN) * kLDK;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
     constexpr int PATCHES = (THREADS / 64) * 32 * kPatchLD;                      // epilogue transpose patches, one per wave
     constexpr int SMEM = NBUF * STAGE > PATCHES ? NBUF * STAGE : PATCHES;
@@ -164,14 +206,22 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
             a_base[i] = 0;
         }
     }
-    unsigned b_base[B_ROWS];
+    constexpr int B_BASES = PREC ? B_TASKS : B_ROWS;
+    unsigned b_base[B_BASES];
+    const int kgroups = (p.K + 7) / 8;                 // bf16x3: 8-k groups per weight row (the pack pads K to a multiple of 8)
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i) {
-        const int n = n0 + r0 + RPP * i;
-        b_base[i] = n < p.Cout ? (unsigned)n * (unsigned)p.K * 4u : kOOB;
+    for (int i = 0; i < B_BASES; ++i) {
+        if constexpr (PREC == 0) {
+            const int n = n0 + r0 + RPP * i;
+            b_base[i] = n < p.Cout ? (unsigned)n * (unsigned)p.K * 4u : kOOB;
+        } else {
+            const int t = tid + THREADS * i, n = n0 + t / GPR;
+            b_base[i] = (t < BN * GPR && n < p.Cout) ? (unsigned)n * (unsigned)kgroups * 48u + (unsigned)(t % GPR) * 48u : kOOB;
+        }
     }
 
-    int k = kt_begin * kBK + c4;  // this thread's k for the K-step being loaded
+    int kq = kt_begin;               // K-step being loaded
+    int k = kt_begin * kBK + c4;     // this thread's k for the A chunk of that K-step
 
     // Two register staging sets: the loads of K-step kt+2 are issued while step kt computes and are only
     // written to LDS at the end of step kt+1, so a workgroup tolerates ~2 K-steps of memory latency (a lone
@@ -191,17 +241,57 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
             const bool ok = kin && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
             ra[i] = buffer_load4(rs_in, ok ? a_base[i] + delta : kOOB);
         }
+        if constexpr (PREC == 0) {
 #pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) rb[i] = buffer_load4(rs_w, (kin && b_base[i] != kOOB) ? b_base[i] + (unsigned)k * 4u : kOOB);
+            for (int i = 0; i < B_ROWS; ++i) rb[i] = buffer_load4(rs_w, (kin && b_base[i] != kOOB) ? b_base[i] + (unsigned)k * 4u : kOOB);
+        } else {
+            const unsigned goff = (unsigned)kq * (unsigned)(GPR * 48);
+#pragma unroll
+            for (int i = 0; i < B_TASKS; ++i) {
+                const bool ok = b_base[i] != kOOB && kq * GPR + (tid + THREADS * i) % GPR < kgroups;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) rb[3 * i + q] = buffer_load4(rs_w, ok ? b_base[i] + goff + 16u * q : kOOB);
+            }
+        }
         k += kBK;
+        ++kq;
+    };
+    // one staged A chunk (4 consecutive k of one row) -> LDS; f32 B chunks go the same way (operand 1)
+    auto store_chunk = [&](int buf, int operand, int row, const float4 &v) {
+        float *base = smem + buf * STAGE + (operand ? kPlanes * BM * kLDK : 0);
+        if constexpr (PREC == 0) {
+            *reinterpret_cast<float4 *>(base + row * kLDK + c4) = v;
+        } else {
+            unsigned h[2], m[2], l[2];
+            split3_pair(v.x, v.y, h[0], m[0], l[0]);
+            split3_pair(v.z, v.w, h[1], m[1], l[1]);
+            unsigned char *b = reinterpret_cast<unsigned char *>(base) + row * (kLDK * 4) + c4 * 2;
+            *reinterpret_cast<uint2 *>(b) = make_uint2(h[0], h[1]);
+            *reinterpret_cast<uint2 *>(b + BM * (kLDK * 4)) = make_uint2(m[0], m[1]);
+            *reinterpret_cast<uint2 *>(b + 2 * BM * (kLDK * 4)) = make_uint2(l[0], l[1]);
+        }
+    };
+    auto store_b = [&](int buf, const float4(&rb)[B_ROWS]) {
+        if constexpr (PREC == 0) {
+#pragma unroll
+            for (int i = 0; i < B_ROWS; ++i) store_chunk(buf, 1, r0 + RPP * i, rb[i]);
+        } else {
+            unsigned char *base = reinterpret_cast<unsigned char *>(smem + buf * STAGE + kPlanes * BM * kLDK);
+#pragma unroll
+            for (int i = 0; i < B_TASKS; ++i) {
+                const int t = tid + THREADS * i;
+                if (t < BN * GPR) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        *reinterpret_cast<float4 *>(base + q * BN * (kLDK * 4) + (t / GPR) * (kLDK * 4) + (t % GPR) * 16) = rb[3 * i + q];
+                }
+            }
+        }
     };
     auto store_lds = [&](int buf, const float4(&ra)[A_ROWS], const float4(&rb)[B_ROWS]) {
-        float *As = smem + buf * STAGE;
-        float *Bs = As + BM * kLDK;
 #pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<float4 *>(As + (r0 + RPP * i) * kLDK + c4) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<float4 *>(Bs + (r0 + RPP * i) * kLDK + c4) = rb[i];
+        for (int i = 0; i < A_ROWS; ++i) store_chunk(buf, 0, r0 + RPP * i, ra[i]);
+        store_b(buf, rb);
     };
 
     f32x16 acc[TM][TN];
@@ -223,6 +313,56 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     //   the LDS writes of step kt+1 are issued behind the first MFMA group and complete under the rest.
     auto kstep = [&](int buf, bool do_load, float4(&lra)[A_ROWS], float4(&lrb)[B_ROWS], bool do_store,
                      const float4(&sra)[A_ROWS], const float4(&srb)[B_ROWS]) {
+        if constexpr (PREC == 1) {
+            // bf16x3: per 16-k chunk a lane reads ONE ds_read_b128 per plane and 32-row block = 8 consecutive bf16 of row
+            // (lane & 31) at k = 16 * chunk + 8 * (lane >> 5); six MFMAs per (A block, B block), smallest products first
+            constexpr int ROW_B = kLDK * 4, CHUNKS = kBK / 16;
+            const unsigned char *As = reinterpret_cast<const unsigned char *>(smem + buf * STAGE) +
+                                      (wm * WM + frag_row) * ROW_B + (lane >> 5) * 16;
+            const unsigned char *Bs = reinterpret_cast<const unsigned char *>(smem + buf * STAGE + kPlanes * BM * kLDK) +
+                                      (wn * WN + frag_row) * ROW_B + (lane >> 5) * 16;
+            bf16x8 fa[TM][3], fb[TN][3];
+            auto load_frags = [&](int c) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        fa[i][q] = *reinterpret_cast<const bf16x8 *>(As + q * BM * ROW_B + i * 32 * ROW_B + c * 32);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        fb[j][q] = *reinterpret_cast<const bf16x8 *>(Bs + q * BN * ROW_B + j * 32 * ROW_B + c * 32);
+            };
+            load_frags(0);
+            if (do_load) load_global(lra, lrb);
+#pragma unroll
+            for (int c = 0; c < CHUNKS; ++c) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        f32x16 t = acc[i][j];
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], t, 0, 0, 0);   // lo  * hi
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], t, 0, 0, 0);   // hi  * lo
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], t, 0, 0, 0);   // mid * mid
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], t, 0, 0, 0);   // mid * hi
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], t, 0, 0, 0);   // hi  * mid
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], t, 0, 0, 0);   // hi  * hi
+                        acc[i][j] = t;
+                    }
+                if (c + 1 < CHUNKS) load_frags(c + 1);
+                if (do_store) {                       // the next step's split + LDS writes ride behind this chunk's MFMAs
+                    if (c == 0) {
+#pragma unroll
+                        for (int q = 0; q < A_ROWS; ++q) store_chunk(buf ^ 1, 0, r0 + RPP * q, sra[q]);
+                    }
+                    if (c == CHUNKS - 1) store_b(buf ^ 1, srb);
+                }
+            }
+            __syncthreads();
+            return;
+        }
         const float *As = smem + buf * STAGE + a_frag_off;
         const float *Bs = smem + buf * STAGE + b_frag_off;
         float4 fa[2][TM], fb[2][TN];
@@ -250,22 +390,14 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
                 }
             if (do_store) {
-                // the A_ROWS + B_ROWS LDS writes of the next step are dealt out over this step's sub-steps, one share
-                // behind each MFMA group: a 16 KB burst right after the barrier stalls the fragment reads of the
-                // other workgroups on the CU (probe: halving the burst recovers ~90 % of the LDS-write cost)
-                // the two operands' LDS writes go out behind different MFMA groups: one 16 KB burst right after the
-                // barrier stalls the fragment reads of the other workgroups on the CU (+2-4 % on the two-stage tiles)
+                // the two operands' LDS writes of the next step go out behind different MFMA groups: one 16 KB burst right
+                // after the barrier stalls the fragment reads of the other workgroups on the CU (+2-4 % on the two-stage tiles)
                 constexpr int SUB = kBK / 8;
-                float *As = smem + (buf ^ 1) * STAGE;
-                float *Bs = As + BM * kLDK;
                 if (ks == 0) {
 #pragma unroll
-                    for (int q = 0; q < A_ROWS; ++q) *reinterpret_cast<float4 *>(As + (r0 + RPP * q) * kLDK + c4) = sra[q];
+                    for (int q = 0; q < A_ROWS; ++q) store_chunk(buf ^ 1, 0, r0 + RPP * q, sra[q]);
                 }
-                if (ks == (SUB > 2 ? 2 : SUB - 1)) {
-#pragma unroll
-                    for (int q = 0; q < B_ROWS; ++q) *reinterpret_cast<float4 *>(Bs + (r0 + RPP * q) * kLDK + c4) = srb[q];
-                }
+                if (ks == (SUB > 2 ? 2 : SUB - 1)) store_b(buf ^ 1, srb);
             }
         }
         __syncthreads();
@@ -507,12 +639,47 @@ pack_weight_kernel(const float *__restrict__ w, int Cout, int Cin_src, int KH, i
     }
 }
 
-struct TileInfo { int bm, bn, threads, resident; float cost; int bk; };   // resident = workgroups per CU (LDS / VGPR bound)
+// f32 packed weights [Cout][K] -> bf16x3 [Cout][ceil(K/8)][hi|mid|lo][8]: each weight cut EXACTLY into three bf16 pieces by
+// truncation (hi + mid + lo == w); k beyond K is zero.  One thread per 8-k group.
+__global__ void __launch_bounds__(256)
+pack_weight_bf16x3_kernel(const float *__restrict__ w, int Cout, int K, unsigned *__restrict__ out) {
+    const int groups = (K + 7) / 8;
+    const long total = (long)Cout * groups;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(t % groups);
+        const long n = t / groups;
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = g * 8 + e;
+            split3(k < K ? w[n * K + k] : 0.f, h[e], m[e], l[e]);
+        }
+        unsigned *o = out + t * 12;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = pack2(h[2 * e], h[2 * e + 1]);
+            o[4 + e] = pack2(m[2 * e], m[2 * e + 1]);
+            o[8 + e] = pack2(l[2 * e], l[2 * e + 1]);
+        }
+    }
+}
+
+struct TileInfo { int bm, bn, threads, resident; float cost; int bk, nbuf, bf16x3; };   // resident = workgroups per CU (LDS / VGPR bound)
 const TileInfo kTiles[TSOD_TILE_COUNT] = {
-    {0, 0, 0, 0, 0.f, 32},        {128, 128, 256, 2, 1.00f, 32}, {128, 64, 256, 2, 1.06f, 32}, {64, 64, 256, 4, 1.15f, 32},
-    {64, 128, 256, 2, 1.06f, 32}, {128, 128, 512, 2, 1.00f, 32}, {128, 64, 512, 2, 1.06f, 32}, {256, 128, 512, 1, 0.98f, 32},
-    {64, 64, 256, 6, 1.20f, 32},  {128, 64, 512, 3, 1.10f, 32},  {64, 64, 256, 4, 1.10f, 64},  {128, 64, 512, 2, 1.05f, 64},
-    {64, 64, 64, 8, 1.40f, 32},   {128, 64, 128, 4, 1.35f, 32}, {128, 64, 256, 4, 1.12f, 32}, {64, 128, 256, 4, 1.12f, 32}};
+    {0, 0, 0, 0, 0.f, 32, 2, 0},        {128, 128, 256, 2, 1.00f, 32, 2, 0}, {128, 64, 256, 2, 1.06f, 32, 2, 0}, {64, 64, 256, 4, 1.15f, 32, 2, 1},
+    {64, 128, 256, 2, 1.06f, 32, 2, 0}, {128, 128, 512, 2, 1.00f, 32, 2, 0}, {128, 64, 512, 2, 1.06f, 32, 2, 0}, {256, 128, 512, 1, 0.98f, 32, 2, 0},
+    {64, 64, 256, 6, 1.20f, 32, 1, 1},  {128, 64, 512, 3, 1.10f, 32, 1, 1},  {64, 64, 256, 4, 1.10f, 64, 1, 1},  {128, 64, 512, 2, 1.05f, 64, 1, 0},
+    {64, 64, 64, 8, 1.40f, 32, 1, 0},   {128, 64, 128, 4, 1.35f, 32, 1, 0}, {128, 64, 256, 4, 1.12f, 32, 1, 1}, {64, 128, 256, 4, 1.12f, 32, 1, 1}};
+// bf16x3 = 1: the tile also exists as a bf16x3 variant (three bf16 planes per operand fit the 64 KB of static LDS)
+
+// workgroups per CU: the f32 figure (VGPR / LDS bound), for bf16x3 additionally capped by its larger LDS footprint
+int residency(int tile, int prec) {
+    const TileInfo &t = kTiles[tile];
+    if (!prec) return t.resident;
+    const int lds = t.nbuf * 3 * (t.bm + t.bn) * (t.bk / 2 + 4) * 4;
+    const int fit = 160 * 1024 / lds;
+    return fit < t.resident ? (fit < 1 ? 1 : fit) : t.resident;
+}
 
 int validate(const tsod_conv2d_desc *d) {
     TSOD_REQUIRE(d != nullptr, TSOD_ERR_INVALID_ARG);
@@ -531,6 +698,8 @@ int validate(const tsod_conv2d_desc *d) {
                  TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->act >= TSOD_ACT_NONE && d->act <= TSOD_ACT_RELU, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->tile >= 0 && d->tile < TSOD_TILE_COUNT && d->split_k >= -1 && d->split_k <= 64, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->precision == TSOD_PREC_BF16X3, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->tile == TSOD_TILE_AUTO || kTiles[d->tile].bf16x3, TSOD_ERR_UNSUPPORTED);
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
     TSOD_REQUIRE(M < (int64_t)INT_MAX, TSOD_ERR_UNSUPPORTED);
     return TSOD_OK;
@@ -557,9 +726,6 @@ int cu_count() {
     return g_cu_count;
 }
 
-// Workgroups that fit on one CU at a time (LDS-bound: 2 stages of (BM+BN) x 36 floats out of 160 KiB).
-int residency(int tile) { return kTiles[tile].resident; }
-
 constexpr size_t kTicketBytes = 256 * 1024;   // tickets for up to 65536 K-sliced tiles per launch
 
 struct Sched {
@@ -580,7 +746,7 @@ Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
     s.tile = tile; s.bm = kTiles[tile].bm; s.bn = kTiles[tile].bn;
     s.tiles_m = (int)tsod_cdiv(M, s.bm); s.tiles_n = (int)tsod_cdiv(d->Cout, s.bn);
     s.tiles = s.tiles_m * s.tiles_n;
-    const int slots = cu_count() * residency(tile);
+    const int slots = cu_count() * residency(tile, d->precision);
     int split = 1, dp = s.tiles;
     if (mode > 1) {
         split = mode < ksteps ? mode : ksteps;
@@ -610,7 +776,7 @@ Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
 
     // cost, in cycles of the most loaded CU: co-resident workgroups share the CU's matrix pipes, so a wave of
     // workgroups costs (workgroups per CU) x (K-steps x BM*BN/4 MFMA cycles + fixed prologue/epilogue)
-    const double step = (double)s.bm * s.bn / 4.0 * kTiles[tile].cost * (bk / 32);
+    const double step = (double)s.bm * s.bn / 4.0 * kTiles[tile].cost * (bk / 32) * (d->precision ? 0.55 : 1.0);
     const double fixed = 3000.0 + (double)s.bm * s.bn / 8.0;
     const int cus = cu_count();
     double c = (double)tsod_cdiv(dp, cus) * (ksteps * step + fixed);
@@ -626,6 +792,7 @@ Sched resolve(const tsod_conv2d_desc *d) {
     best.cost = 1e300;
     for (int t = 1; t < TSOD_TILE_COUNT; ++t) {
         if (d->tile != TSOD_TILE_AUTO && d->tile != t) continue;
+        if (d->precision && !kTiles[t].bf16x3) continue;
         if (d->split_k != 0) {
             const Sched s = make_sched(d, t, d->split_k);
             if (s.cost < best.cost) best = s;
@@ -642,9 +809,9 @@ Sched resolve(const tsod_conv2d_desc *d) {
     return best;
 }
 
-template <int BM, int BN, int WM, int WN, int MW, int NBUF = 2, int BK = 32>
+template <int BM, int BN, int WM, int WN, int MW, int NBUF = 2, int BK = 32, int PREC = 0>
 void launch_tile(const ConvParams &p, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MW, NBUF, BK>), dim3(grid), dim3(64 * (BM / WM) * (BN / WN)), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MW, NBUF, BK, PREC>), dim3(grid), dim3(64 * (BM / WM) * (BN / WN)), 0, s, p);
 }
 
 }  // namespace
@@ -691,7 +858,9 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
     p.K = d->KH * d->KW * p.Cin;
     {
         const uint64_t in_bytes = (uint64_t)d->N * d->H * d->W * d->in_pitch * sizeof(float);
-        const uint64_t w_bytes = (uint64_t)d->Cout * p.K * sizeof(float);
+        // bf16x3 weights are pre-split: [Cout][ceil(K/8)][hi|mid|lo][8] bf16 = 48 bytes per 8 k (tsod_pack_conv_weight_bf16x3)
+        const uint64_t w_bytes = d->precision == TSOD_PREC_BF16X3 ? (uint64_t)d->Cout * ((p.K + 7) / 8) * 48
+                                                                  : (uint64_t)d->Cout * p.K * sizeof(float);
         const uint64_t out_bytes = (uint64_t)p.M * d->out_pitch * sizeof(float);
         const uint64_t res_bytes = residual ? (uint64_t)p.M * d->res_pitch * sizeof(float) : 0;
         // 32-bit buffer offsets: one activation tensor must stay below 4 GiB (shard the batch otherwise)
@@ -721,6 +890,17 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
     p.part_bytes = (unsigned)(sc.ws_bytes - sc.ticket_bytes);
     TSOD_REQUIRE(sc.ws_bytes < 0xFFFFFFF0ull, TSOD_ERR_UNSUPPORTED);
     hipStream_t s = tsod_stream(stream);
+    if (d->precision == TSOD_PREC_BF16X3) {
+        switch (sc.tile) {
+            case TSOD_TILE_64x64_S1: launch_tile<64, 64, 32, 32, 5, 1, 32, 1>(p, sc.grid, s); break;
+            case TSOD_TILE_128x64_W8_S1: launch_tile<128, 64, 32, 32, 3, 1, 32, 1>(p, sc.grid, s); break;
+            case TSOD_TILE_64x64_S1_K64: launch_tile<64, 64, 32, 32, 2, 1, 64, 1>(p, sc.grid, s); break;
+            case TSOD_TILE_128x64_S1: launch_tile<128, 64, 64, 32, 3, 1, 32, 1>(p, sc.grid, s); break;
+            case TSOD_TILE_64x128_S1: launch_tile<64, 128, 32, 64, 3, 1, 32, 1>(p, sc.grid, s); break;
+            default: launch_tile<64, 64, 32, 32, 2, 2, 32, 1>(p, sc.grid, s); break;      // TSOD_TILE_64x64 (two LDS stages)
+        }
+        return tsod_launch_status();
+    }
     switch (sc.tile) {
         case TSOD_TILE_128x128: launch_tile<128, 128, 64, 64, 2>(p, sc.grid, s); break;
         case TSOD_TILE_128x64: launch_tile<128, 64, 64, 32, 2>(p, sc.grid, s); break;
@@ -769,6 +949,22 @@ extern "C" int tsod_pack_conv_weight_f32(const float *w_oihw, int32_t Cout, int3
     const int blocks = (int)(tsod_cdiv(total, 256) < 4096 ? tsod_cdiv(total, 256) : 4096);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), w_oihw, Cout, Cin_src, KH,
                        KW_src, Cin, KW, w_packed);
+    return tsod_launch_status();
+}
+
+extern "C" size_t tsod_conv_weight_bf16x3_bytes(int32_t Cout, int32_t K) {
+    if (Cout <= 0 || K <= 0) return 0;
+    return (size_t)Cout * ((K + 7) / 8) * 48;
+}
+
+extern "C" int tsod_pack_conv_weight_bf16x3(const float *w_packed, int32_t Cout, int32_t K, void *w_bf16x3, tsod_stream_t stream) {
+    TSOD_REQUIRE(w_packed && w_bf16x3, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(Cout > 0 && K > 0, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(tsod_aligned16(w_bf16x3), TSOD_ERR_ALIGNMENT);
+    const long total = (long)Cout * ((K + 7) / 8);
+    const int blocks = (int)(tsod_cdiv(total, 256) < 4096 ? tsod_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), w_packed, Cout, K,
+                       static_cast<unsigned *>(w_bf16x3));
     return tsod_launch_status();
 }
 

@@ -56,6 +56,16 @@ class PackedConv:
         return ((H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw_logical) // self.stride + 1)
 
 
+def weights_bf16x3(pc) -> torch.Tensor:
+    """The pre-split bf16x3 image of a packed layer's weights (PackedConv or a compatible holder), made on first use and
+    kept beside the f32 weights."""
+    w3 = getattr(pc, "w3", None)
+    if w3 is None:
+        from . import hip_ops
+        w3 = pc.w3 = hip_ops.pack_conv_weight_bf16x3(pc.w)
+    return w3
+
+
 def prelu_slope(m: torch.nn.PReLU) -> float:
     if m.weight.numel() != 1:
         raise TsodError("only single-parameter nn.PReLU is supported (what the reference uses)")
@@ -99,7 +109,13 @@ def _merge_adjacent(segs):
 
 # --------------------------------------------------------------------------- plan
 class ConvStep:
-    __slots__ = ("desc", "args", "name", "flops", "ws_bytes")
+    __slots__ = ("desc", "args", "name", "flops", "ws_bytes", "pc")
+
+    def choose(self, tile: int, split_k: int, precision: int):
+        """Pin (tile, K-slice schedule, arithmetic); the weight argument follows the arithmetic (f32 or pre-split bf16x3)."""
+        d = self.desc
+        d.tile, d.split_k, d.precision = int(tile), int(split_k), int(precision)
+        self.args[2] = ptr(weights_bf16x3(self.pc)) if precision == _ffi.PREC_BF16X3 else ptr(self.pc.w)
 
 
 class Plan:
@@ -107,6 +123,7 @@ class Plan:
         self.device = torch.device(device)
         self.pool = BufferPool(self.device)
         self._packed = packed if packed is not None else {}   # the owner's packed-weight cache (shared by all its plans)
+        self.precision = 0                   # default arithmetic of the plan's dense convs (_ffi.PREC_F32 / PREC_BF16X3)
         self._retired: list = []             # outgrown workspaces: graphs captured earlier still hold their pointers
         self.steps: list[list] = []          # [cfunc, [args...]]
         self.conv_steps: list[ConvStep] = []
@@ -136,11 +153,12 @@ class Plan:
     MAX_TENSOR_BYTES = 0xF0000000
 
     def conv(self, pc: PackedConv, x: torch.Tensor, out: torch.Tensor, *, segs=None, out_off=0, residual=None,
-             name="conv", tile=0, split_k=0):
+             name="conv", tile=0, split_k=0, precision=None):
         """x [N,H,W,P] -> out [N,OH,OW,Pout] (channel slice [out_off, out_off+Cout))."""
         N, H, W, P = x.shape
         OH, OW = pc.out_hw(H, W)
         assert tuple(out.shape[:3]) == (N, OH, OW), (out.shape, (N, OH, OW))
+        precision = self.precision if precision is None else precision
         per_img = max(H * W * P, OH * OW * out.shape[3], 0 if residual is None else OH * OW * residual.shape[3]) * 4
         if N > 1 and per_img * N >= self.MAX_TENSOR_BYTES:
             group = max(1, self.MAX_TENSOR_BYTES // per_img)
@@ -148,17 +166,18 @@ class Plan:
                 n1 = min(N, n0 + group)
                 self.conv(pc, x[n0:n1], out[n0:n1], segs=segs, out_off=out_off,
                           residual=None if residual is None else residual[n0:n1], name=f"{name}[{n0}:{n1}]", tile=tile,
-                          split_k=split_k)
+                          split_k=split_k, precision=precision)
             return out
         segs = [(0, pc.cin)] if segs is None else _merge_adjacent(segs)
         d = make_conv_desc(N=N, H=H, W=W, in_pitch=P, segs=segs, Cout=pc.cout, out_pitch=out.shape[3], out_off=out_off,
                            KH=pc.kh, KW=pc.kw, stride=pc.stride, pad_h=pc.pad, pad_w=pc.pad, OH=OH, OW=OW, act=pc.act,
                            slope=pc.slope, res_pitch=0 if residual is None else residual.shape[3], res_off=0,
-                           tile=tile, split_k=split_k)
-        args = [byref(d), ptr(x), ptr(pc.w), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out), 0, 0]
+                           tile=tile, split_k=split_k, precision=precision)
+        args = [byref(d), ptr(x), ptr(weights_bf16x3(pc)) if precision == _ffi.PREC_BF16X3 else ptr(pc.w), ptr(pc.scale),
+                ptr(pc.shift), ptr(residual), ptr(out), 0, 0]
         self.steps.append([lib().tsod_conv2d_f32, args])
         st = ConvStep()
-        st.desc, st.args, st.name = d, args, name
+        st.desc, st.args, st.name, st.pc = d, args, name, pc
         st.flops = 2 * N * OH * OW * getattr(pc, "cout_real", pc.cout) * pc.kh * pc.kw_logical * pc.cin_src   # algorithmic
         st.ws_bytes = 0
         self.conv_steps.append(st)
@@ -212,13 +231,15 @@ class Plan:
         return self
 
     # -- tile autotuning ----------------------------------------------------------------------
-    def autotune(self, reps: int = 3, verbose: bool = False, splits=None, concurrent: int = 1):
+    def autotune(self, reps: int = 3, verbose: bool = False, splits=None, concurrent: int = 1, precisions=None):
         """Measure every (tile, split_k) candidate of every conv step on the real buffers with HIP
         events and keep the fastest.  Purely a speed choice: every candidate computes the same sums
         in the same k order per slab; only slab boundaries move.
         ``concurrent`` > 1 times each candidate as that many copies in flight on separate streams
         (per-copy time = elapsed / copies): the objective of a server that overlaps requests, where a
-        schedule that fills the whole chip for one launch is not automatically the cheapest."""
+        schedule that fills the whole chip for one launch is not automatically the cheapest.
+        ``precisions``: the arithmetics to choose from per layer (default: only what each step has now; (0, 1) lets the
+        f32-MFMA and the bf16x3 form of a layer compete - both are f32-accurate, see include/tsod.h)."""
         self.graph = None
         concurrent = max(1, int(concurrent))
         bigs = [torch.zeros(512 << 20, dtype=torch.uint8, device=self.device) for _ in range(concurrent)]   # zero tickets
@@ -231,19 +252,20 @@ class Plan:
             ksteps = (K + 31) // 32
             M = d.N * d.OH * d.OW
             cands = []
-            for tile in _ffi.TILE_IDS:
-                for split in (splits or (1, -1, 2, 3, 4, 6, 8, 12, 16, 24, 32)):
-                    if split > 1 and ksteps // split < 2:
-                        continue
-                    d.tile, d.split_k = tile, split
-                    if lib().tsod_conv2d_workspace_bytes(byref(d)) > big.numel():   # exact need of THIS (tile, split)
-                        continue
-                    cands.append((tile, split))
+            for prec in (precisions if precisions is not None else (int(d.precision),)):
+                for tile in (_ffi.BF16X3_TILE_IDS if prec == _ffi.PREC_BF16X3 else _ffi.TILE_IDS):
+                    for split in (splits or (1, -1, 2, 3, 4, 6, 8, 12, 16, 24, 32)):
+                        if split > 1 and ksteps // split < 2:
+                            continue
+                        st.choose(tile, split, prec)
+                        if lib().tsod_conv2d_workspace_bytes(byref(d)) > big.numel():   # exact need of THIS candidate
+                            continue
+                        cands.append((tile, split, prec))
             best = None
-            args = list(st.args)
-            args[7], args[8] = ptr(big), big.numel()
-            for tile, split in cands:
-                d.tile, d.split_k = tile, split
+            for tile, split, prec in cands:
+                st.choose(tile, split, prec)
+                args = list(st.args)
+                args[7], args[8] = ptr(big), big.numel()
                 s = stream_ptr()
                 rc = lib().tsod_conv2d_f32(*args, s)          # warm
                 if rc != 0:
@@ -275,30 +297,31 @@ class Plan:
                     continue
                 t = e0.elapsed_time(e1) / (reps * concurrent)
                 if best is None or t < best[0]:
-                    best = (t, tile, split)
+                    best = (t, tile, split, prec)
             if best is None:
                 raise TsodError(f"autotune: no runnable (tile, split) candidate for {st.name}")
-            d.tile, d.split_k = best[1], best[2]
-            results.append((st.name, best[0], best[1], best[2], st.flops))
+            st.choose(best[1], best[2], best[3])
+            results.append((st.name, best[0], best[1], best[2], st.flops, best[3]))
             if verbose:
-                print(f"  {st.name:34s} {TILE_NAMES[best[1]]:8s} split {best[2]:3d}  {best[0] * 1e3:8.1f} us "
+                print(f"  {st.name:34s} {TILE_NAMES[best[1]]:8s} split {best[2]:3d} {_ffi.PREC_NAMES[best[3]]:6s} {best[0] * 1e3:8.1f} us "
                       f"{st.flops / best[0] / 1e9:7.1f} TF/s")
         del big, bigs
         self.finalize()
         return results
 
     def export_tiles(self):
-        """[(name, tile, split_k), ...] as currently pinned in the descriptors (0 / 0 = heuristic)."""
-        return [(st.name, int(st.desc.tile), int(st.desc.split_k)) for st in self.conv_steps]
+        """[(name, tile, split_k, precision), ...] as currently pinned in the descriptors (tile 0 / split 0 = heuristic)."""
+        return [(st.name, int(st.desc.tile), int(st.desc.split_k), int(st.desc.precision)) for st in self.conv_steps]
 
     def import_tiles(self, tiles):
-        """Pin (tile, split_k) choices saved by export_tiles (same plan geometry)."""
+        """Pin (tile, split_k[, precision]) choices saved by export_tiles (same plan geometry; 3-tuples = f32)."""
         if len(tiles) != len(self.conv_steps):
             raise TsodError("tile table does not match this plan")
-        for st, (name, tile, split) in zip(self.conv_steps, tiles):
+        for st, row in zip(self.conv_steps, tiles):
+            name, tile, split = row[0], row[1], row[2]
             if name != st.name:
                 raise TsodError(f"tile table mismatch: {name} vs {st.name}")
-            st.desc.tile, st.desc.split_k = int(tile), int(split)
+            st.choose(tile, split, int(row[3]) if len(row) > 3 else 0)
         return self.finalize()
 
     def tile_choices(self):
@@ -328,6 +351,16 @@ class PlanOwner:
     * ``weights_version`` counts invalidations: a graph captured by ``FasterRCNN.make_graphed`` refuses to replay once it
       is stale (it would run the old folded weights)."""
     max_plans = 8
+    conv_precision = "f32"       # "f32" | "bf16x3": default arithmetic of the dense convs of plans built from now on
+
+    def set_conv_precision(self, precision: str):
+        """Arithmetic of the dense conv GEMMs: "f32" (v_mfma_f32_32x32x2_f32) or "bf16x3" (three exact bf16 pieces per
+        operand, six bf16 MFMAs per 16 k: f32-accurate, less matrix-pipe time).  Existing plans are dropped."""
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError(precision)
+        self.conv_precision = precision
+        self.__dict__["_plans"] = OrderedDict()
+        return self
 
     def _init_plan_owner(self):
         self.__dict__["_plans"] = OrderedDict()

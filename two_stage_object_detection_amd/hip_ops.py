@@ -118,8 +118,36 @@ def pack_conv_weight(w: torch.Tensor, cin_pad: int | None = None, kw_pad: int | 
     return out
 
 
+def pack_conv_weight_bf16x3(w_packed: torch.Tensor) -> torch.Tensor:
+    """f32 packed weights [Cout,KH,KW,Cin] -> the pre-split bf16x3 image tsod_conv2d_f32 reads with precision = bf16x3
+    (uint8 tensor of tsod_conv_weight_bf16x3_bytes: [Cout][ceil(K/8)][hi|mid|lo][8] bf16)."""
+    require_cuda(w_packed, "pack_conv_weight_bf16x3")
+    w_packed = w_packed.contiguous()
+    cout = w_packed.shape[0]
+    K = w_packed.numel() // cout
+    out = torch.empty(lib().tsod_conv_weight_bf16x3_bytes(cout, K), dtype=torch.uint8, device=w_packed.device)
+    check(lib().tsod_pack_conv_weight_bf16x3(ptr(w_packed), cout, K, ptr(out), stream_ptr()), "pack_conv_weight_bf16x3")
+    return out
+
+
+_W3_CACHE: dict = {}
+
+
+def _w3_for(w_packed: torch.Tensor) -> torch.Tensor:
+    """Pre-split image of a weight tensor for the tensor-level wrapper (the engine keeps its own per layer)."""
+    key = (w_packed.data_ptr(), tuple(w_packed.shape), w_packed._version)
+    hit = _W3_CACHE.get(key)
+    if hit is None or hit[0]() is not w_packed:
+        import weakref
+        if len(_W3_CACHE) > 64:
+            _W3_CACHE.clear()
+        hit = _W3_CACHE[key] = (weakref.ref(w_packed), pack_conv_weight_bf16x3(w_packed))
+    return hit[1]
+
+
 def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_logical=None, scale=None, shift=None,
-                residual=None, act=ACT_NONE, slope=0.0, segs=None, out=None, out_off=0, tile=0, split_k=0) -> torch.Tensor:
+                residual=None, act=ACT_NONE, slope=0.0, segs=None, out=None, out_off=0, tile=0, split_k=0,
+                precision=0) -> torch.Tensor:
     """Implicit-GEMM convolution on an NHWC tensor [N,H,W,P].  ``w_packed`` is [Cout,KH,KW,Cin]
     (see pack_conv_weight); ``kw_logical`` is the filter width before zero-tap padding (it fixes OW).
     ``segs`` = [(channel offset, length), ...] inside the P-wide pixel (default: the first Cin
@@ -137,10 +165,12 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
     assert out.is_contiguous() and out.shape[:3] == (N, OH, OW)
     d = make_conv_desc(N=N, H=H, W=W, in_pitch=P, segs=segs, Cout=Cout, out_pitch=out.shape[3], out_off=out_off,
                        KH=KH, KW=KW, stride=stride, pad_h=pad, pad_w=pad, OH=OH, OW=OW, act=act, slope=slope,
-                       res_pitch=0 if residual is None else residual.shape[-1], res_off=0, tile=tile, split_k=split_k)
+                       res_pitch=0 if residual is None else residual.shape[-1], res_off=0, tile=tile, split_k=split_k,
+                       precision=precision)
     ws_bytes = lib().tsod_conv2d_workspace_bytes(byref(d))
     ws = CONV_ARENA.get(x.device, ws_bytes) if ws_bytes else None
-    check(lib().tsod_conv2d_f32(byref(d), ptr(x), ptr(w_packed), ptr(scale), ptr(shift), ptr(residual), ptr(out),
+    w_arg = _w3_for(w_packed) if precision == _ffi.PREC_BF16X3 else w_packed     # bf16x3 reads the pre-split weight image
+    check(lib().tsod_conv2d_f32(byref(d), ptr(x), ptr(w_arg), ptr(scale), ptr(shift), ptr(residual), ptr(out),
                                 ptr(ws), ws_bytes, stream_ptr()), "conv2d")
     return out
 

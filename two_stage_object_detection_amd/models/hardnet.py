@@ -212,6 +212,7 @@ class HarDNetFeatureExtraction(PlanOwner, nn.Module):
             raise TsodError("depth_wise=False HarDNet (max-pool variant) has no HIP path; the reference only "
                             "uses depth_wise=True")
         plan = Plan(device, self._packed_cache)
+        plan.precision = 1 if self.conv_precision == "bf16x3" else 0
         L = lib()
         mods = list(self.base)
         x4 = plan.pool.alloc((N, H, W, 4))

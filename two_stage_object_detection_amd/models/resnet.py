@@ -129,6 +129,7 @@ class ResNet(PlanOwner, nn.Module):
         """Launch plan for a [N,3,H,W] input: NCHW->NHWC4, 7x7 stem as a 7x8x4 implicit GEMM with
         BN+PReLU, 3x3/s2 max pool, then the residual stages."""
         plan = Plan(device, self._packed_cache)
+        plan.precision = 1 if self.conv_precision == "bf16x3" else 0
         x4 = plan.pool.alloc((N, H, W, 4))
         plan.input_nhwc = x4
         stem = plan.packed("conv1", lambda: PackedConv(self.conv1.weight, device, bn=self.bn1, stride=2, pad=3, act=ACT_PRELU,
