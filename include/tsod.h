@@ -65,12 +65,12 @@ enum { TSOD_TILE_AUTO = 0, TSOD_TILE_128x128 = 1, TSOD_TILE_128x64 = 2, TSOD_TIL
        TSOD_TILE_128x128_W8 = 5, TSOD_TILE_128x64_W8 = 6, TSOD_TILE_256x128_W8 = 7, TSOD_TILE_64x64_S1 = 8,
        TSOD_TILE_128x64_W8_S1 = 9, TSOD_TILE_64x64_S1_K64 = 10, TSOD_TILE_128x64_W8_S1_K64 = 11,
        TSOD_TILE_64x64_W1_S1 = 12, TSOD_TILE_128x64_W2_S1 = 13, TSOD_TILE_128x64_S1 = 14, TSOD_TILE_64x128_S1 = 15,
-       TSOD_TILE_COUNT = 16 };
+       TSOD_TILE_128x128_S1 = 16, TSOD_TILE_COUNT = 17 };
 /* arithmetic of the contraction.  F32: v_mfma_f32_32x32x2_f32 (a k-ordered f32 fma chain).  BF16X3: every f32 operand cut
  * exactly into three bf16 pieces (hi + mid + lo == x), six piece products per k accumulated in f32 on
  * v_mfma_f32_32x32x16_bf16: f32-level accuracy (error ~1.3e-7 of sum|a*b|) at 0.375x the matrix-pipe time; storage,
  * accumulation and epilogue are f32 either way.  Tiles available in BF16X3: 64x64, 64x64_S1, 128x64_W8_S1, 64x64_S1_K64,
- * 128x64_S1, 64x128_S1 (TSOD_ERR_UNSUPPORTED for the others). */
+ * 128x64_S1, 64x128_S1, 128x128_S1 (TSOD_ERR_UNSUPPORTED for the others). */
 enum { TSOD_PREC_F32 = 0, TSOD_PREC_BF16X3 = 1 };
 /* With TSOD_PREC_BF16X3 the `w_packed` argument of tsod_conv2d_f32 is the PRE-SPLIT weight image made once by
  * tsod_pack_conv_weight_bf16x3 from the f32 packed weights [Cout][K]: [Cout][ceil(K/8)][hi | mid | lo][8] bf16, 48 bytes per

@@ -1,11 +1,18 @@
-"""Run ONE conv shape / tile / split a few times (target of rocprofv3 counter passes)."""
-import sys, torch
-sys.path.insert(0, '/root/repo')
-from two_stage_object_detection_amd import hip_ops
+"""Run ONE conv shape / tile / split / precision a few times (target of rocprofv3 counter passes).
+    python scripts/conv_one.py B H W Cin Cout k tile split reps [precision]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from two_stage_object_detection_amd import hip_ops  # noqa: E402
+
 dev = torch.device('cuda:0')
 B, H, W, Cin, Cout, k, tile, split, reps = [int(v) for v in sys.argv[1:10]]
+prec = int(sys.argv[10]) if len(sys.argv) > 10 else 0
 x = torch.randn(B, H, W, Cin, device=dev)
 w = torch.randn(Cout, k, k, Cin, device=dev) / (Cin * k * k) ** 0.5
 for _ in range(reps):
-    hip_ops.conv2d_nhwc(x, w, pad=k // 2, tile=tile, split_k=split, act=1, slope=0.25)
+    hip_ops.conv2d_nhwc(x, w, pad=k // 2, tile=tile, split_k=split, act=1, slope=0.25, precision=prec)
 torch.cuda.synchronize()

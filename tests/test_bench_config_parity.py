@@ -88,7 +88,7 @@ def test_detector_after_plan_autotune_and_through_the_serving_path(dev, r50):
         res = plan.autotune(reps=2, concurrent=2, precisions=(0, 1))     # bench.py --precision auto: f32 and bf16x3 compete
         tuned = plan.export_tiles()
         assert len(res) == len(plan.conv_steps) == 53
-        assert all(t in range(1, 16) and p in (0, 1) for _, t, _, p in tuned)
+        assert all(t in range(1, 17) and p in (0, 1) for _, t, _, p in tuned)
         got = [o.cpu() for o in model(xg)]
         model.raise_if_error()
         rep = compare_detector_outputs(got, ref)
