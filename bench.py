@@ -30,6 +30,12 @@ Two schedules are measured and BOTH are reported in the one JSON line:
 Every timed region (exactly K steps between barrier + synchronize on both sides, max over ranks) is repeated
 --repeats times (default 5); the median repeat is reported, min / max alongside.
 
+  roofline         : per layer the autotuner picks the arithmetic (--precision auto): f32 MFMA (peak 157.3 TFLOP/s) or bf16x3
+                     (three exact bf16 pieces per operand, six bf16 MFMAs per f32 product: peak 2516.8 / 6 = 419.5 TFLOP/s
+                     f32-equivalent).  achieved = algorithmic f32 conv FLOPs / kernel time; peak = the FLOP-weighted
+                     (harmonic) peak of the layers' arithmetics, so frac = sum of the layers' ideal matrix-pipe times /
+                     measured time.  roofline_f32_mfma is the same measurement with every layer pinned to the f32-MFMA
+                     kernels (the number comparable with round 1).
   roofline.traffic : HBM bytes per conv launch from FETCH_SIZE / WRITE_SIZE, collected by two short `rocprofv3 --pmc`
                      child runs of this script (rank 0, N = 1; --no-pmc skips them).
   cpu_baseline     : the CPU oracle (torch CPU ops + C nms / roi_pool restatement of the reference's path) timed on this
@@ -51,6 +57,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2516.8   # same guide: ~2.5 PF dense bf16 MFMA = 16x the f32 MFMA rate
+# bf16x3 executes SIX bf16 MFMA products per f32 product: its roofline in f32-equivalent (algorithmic) FLOPs
+BF16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 R_POST = 300
 
 
@@ -356,10 +365,10 @@ def main(argv=None):
         plan = model.extractor._plan_for(x)
         default_tiles = plan.export_tiles()
         tiles = {"serial": default_tiles, "in_flight": default_tiles}
+        splits = [int(v) for v in args.autotune_splits.split(",")] if args.autotune_splits else None
         if args.tiles_file and os.path.exists(args.tiles_file):
             tiles = json.load(open(args.tiles_file))
         elif not args.no_autotune:
-            splits = [int(v) for v in args.autotune_splits.split(",")] if args.autotune_splits else None
             precs = {"f32": (0,), "bf16x3": (1,), "auto": (0, 1)}[args.precision]
             plan.autotune(verbose=args.verbose and rank == 0, splits=splits, concurrent=1, precisions=precs)
             tiles["serial"] = plan.export_tiles()
@@ -383,11 +392,31 @@ def main(argv=None):
                 return server.submit()
             return step
 
+        # ---- the f32-MFMA kernels alone (every layer pinned to precision f32): the roofline comparable with round 1
+        f32_leg = None
+        if not args.no_autotune and args.precision != "f32" and not (args.tiles_file and "f32" not in tiles):
+            if "f32" not in tiles:
+                plan.autotune(verbose=False, splits=splits, concurrent=1, precisions=(0,))
+                tiles["f32"] = plan.export_tiles()
+                if args.tiles_file and rank == 0:
+                    json.dump(tiles, open(args.tiles_file, "w"))
+            plan.import_tiles(tiles["f32"])
+            ms32 = conv_event_times(plan)
+            fl32 = sum(st.flops for st in plan.conv_steps)
+            f32_leg = {"bound": "mfma", "achieved": round(fl32 / (sum(ms32) * 1e-3) / 1e12, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+                       "unit": "TFLOP/s", "frac": round(fl32 / (sum(ms32) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                       "kernel_ms_per_forward": round(sum(ms32), 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
+                       "note": "same 53 conv launches with every layer pinned to the f32-MFMA kernels (serial per-kernel "
+                               "HIP-event times); not the timed path when --precision auto picks bf16x3"}
         # ---- schedule 1: strictly serial (one graph, one stream) + the per-kernel roofline that belongs to it
         plan.import_tiles(tiles["serial"])
         conv_ms = conv_event_times(plan)
         conv_flops = sum(st.flops for st in plan.conv_steps)
         algo_bytes = conv_algorithmic_bytes(plan)
+        precs = [int(st.desc.precision) for st in plan.conv_steps]
+        flops_bf = sum(st.flops for st, pr in zip(plan.conv_steps, precs) if pr == 1)
+        ideal_ms = sum(st.flops / ((BF16X3_PEAK_TFLOPS if pr == 1 else F32_MFMA_PEAK_TFLOPS) * 1e12) * 1e3
+                       for st, pr in zip(plan.conv_steps, precs))
         serial_server = InFlightDetector(model, x, depth=1, tiles=tiles["serial"])
         serial = timer.measure(make_step(serial_server, 1), args.steps, args.warmup, args.repeats)
         serial_server.drain()
@@ -422,6 +451,8 @@ def main(argv=None):
         head = fly
         conv_total_ms = sum(conv_ms)
         achieved = conv_flops / (conv_total_ms * 1e-3) / 1e12
+        eff_peak = conv_flops / (ideal_ms * 1e-3) / 1e12               # FLOP-weighted harmonic peak of the layers' arithmetics
+        n_bf = sum(precs)
         traffic, traffic_note = (None, "skipped") if (n_gpus > 1 or args.no_pmc) else pmc_traffic(args, tiles["serial"], len(conv_ms))
         step_flops = conv_flops                                           # conv GEMM FLOPs of one step (B images)
         line = {
@@ -429,7 +460,10 @@ def main(argv=None):
                       else f"images/sec Faster R-CNN {args.backbone} @{args.height}x{args.width}",
             "value": round(n_gpus * B / (head["ms_per_step"] * 1e-3), 3), "unit": "images/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(head["ms_per_step"], 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if n_bf == 0 else "f32 storage/accumulate; conv products as bf16x3 (3 exact bf16 pieces per operand, "
+                                              f"6 bf16 MFMAs per product) in {n_bf} of {len(precs)} conv layers, f32 MFMA in the rest",
+            "data": "synthetic",
             "config": {"workload": f"Full Faster R-CNN {args.backbone} inference forward, batch={B} per GPU, "
                                    f"3x{args.height}x{args.width}, {args.num_classes}+1 classes, 3000->300 proposals"
                                    + (" (BASELINE configs[4]: data-parallel, 8 images per rank)" if world > 1 and B == 8 else ""),
@@ -442,23 +476,29 @@ def main(argv=None):
                        "ms_per_step": round(serial["ms_per_step"], 4), "ms_per_step_min": round(serial["min"], 4),
                        "ms_per_step_max": round(serial["max"], 4), "repeats": serial["n"],
                        "note": "one forward at a time on one stream (--in-flight 1 semantics) = latency of a step"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(eff_peak, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / eff_peak, 4),
+                         "peak_note": f"f32-equivalent: {n_bf} layers bf16x3 (bf16 dense MFMA {BF16_MFMA_PEAK_TFLOPS} / 6 products = "
+                                      f"{BF16X3_PEAK_TFLOPS:.1f}), {len(precs) - n_bf} layers f32 MFMA ({F32_MFMA_PEAK_TFLOPS}); FLOP-weighted "
+                                      "harmonic mean, i.e. frac = sum of ideal matrix-pipe times / measured time",
+                         "executed_bf16_mfma_tflops": round(6.0 * flops_bf / (conv_total_ms * 1e-3) / 1e12, 1),
                          "traffic": None if traffic is None else round(traffic),
                          "traffic_unit": "HBM bytes per conv launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 / launches"
                                          + ("" if traffic_note is None else f" [{traffic_note}]"),
                          "algorithmic_bytes_per_launch": round(algo_bytes / len(conv_ms)),
                          "traffic_over_algorithmic": None if traffic is None else round(traffic * len(conv_ms) / algo_bytes, 3),
-                         "kernel": f"conv_igemm_kernel (f32 MFMA implicit GEMM), {len(conv_ms)} launches per forward",
+                         "kernel": f"conv_igemm_kernel (implicit GEMM, f32 MFMA / bf16x3 MFMA per layer), {len(conv_ms)} launches per forward",
                          "schedule": "serial", "flops_per_forward": conv_flops,
                          "kernel_ms_per_forward": round(conv_total_ms, 4),
                          "serial_ms_per_step": round(serial["ms_per_step"], 4),
                          "share_of_serial_step": round(conv_total_ms / serial["ms_per_step"], 4)},
             "throughput_mode": {"steps_in_flight": n_fly, "conv_tflops_per_step_time": round(step_flops / (head["ms_per_step"] * 1e-3) / 1e12, 3),
-                                "frac_of_peak": round(step_flops / (head["ms_per_step"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                                "frac_of_peak": round(step_flops / (head["ms_per_step"] * 1e-3) / 1e12 / eff_peak, 4),
                                 "note": "conv FLOPs of a step / ms_per_step of the headline schedule: a whole-step bound "
                                         "(non-GEMM kernels included in the time), not a per-kernel measurement"},
         }
+        if f32_leg is not None:
+            line["roofline_f32_mfma"] = f32_leg
         if check is not None:
             line["check"] = check
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -907,8 +907,8 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
             case TSOD_TILE_64x64_S1: launch_tile<64, 64, 32, 32, 5, 1, 32, 1>(p, sc.grid, s); break;
             case TSOD_TILE_128x64_W8_S1: launch_tile<128, 64, 32, 32, 3, 1, 32, 1>(p, sc.grid, s); break;
             case TSOD_TILE_64x64_S1_K64: launch_tile<64, 64, 32, 32, 2, 1, 64, 1>(p, sc.grid, s); break;
-            case TSOD_TILE_128x64_S1: launch_tile<128, 64, 64, 32, 3, 1, 32, 1>(p, sc.grid, s); break;
-            case TSOD_TILE_64x128_S1: launch_tile<64, 128, 32, 64, 3, 1, 32, 1>(p, sc.grid, s); break;
+            case TSOD_TILE_128x64_S1: launch_tile<128, 64, 64, 32, 4, 1, 32, 1>(p, sc.grid, s); break;
+            case TSOD_TILE_64x128_S1: launch_tile<64, 128, 32, 64, 4, 1, 32, 1>(p, sc.grid, s); break;
             case TSOD_TILE_128x128_S1: launch_tile<128, 128, 64, 64, 2, 1, 32, 1>(p, sc.grid, s); break;
             default: launch_tile<64, 64, 32, 32, 2, 2, 32, 1>(p, sc.grid, s); break;      // TSOD_TILE_64x64 (two LDS stages)
         }
