@@ -85,6 +85,8 @@ def parse(argv=None):
     ap.add_argument("--tiles-file", default=None, help="JSON cache of the autotuned (tile, split) tables {'serial': [...], "
                     "'in_flight': [...]}: loaded if present, else written after autotuning (keeps profiler runs free of "
                     "tuning launches)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replays, serial schedule only "
+                    "(for rocprofv3 --pmc passes: every dispatch then carries its own counter sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs behind roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -366,7 +368,8 @@ def main(argv=None):
         default_tiles = plan.export_tiles()
         tiles = {"serial": default_tiles, "in_flight": default_tiles}
         splits = [int(v) for v in args.autotune_splits.split(",")] if args.autotune_splits else None
-        if args.tiles_file and os.path.exists(args.tiles_file):
+        tiles_loaded = bool(args.tiles_file and os.path.exists(args.tiles_file))
+        if tiles_loaded:
             tiles = json.load(open(args.tiles_file))
         elif not args.no_autotune:
             precs = {"f32": (0,), "bf16x3": (1,), "auto": (0, 1)}[args.precision]
@@ -394,7 +397,7 @@ def main(argv=None):
 
         # ---- the f32-MFMA kernels alone (every layer pinned to precision f32): the roofline comparable with round 1
         f32_leg = None
-        if not args.no_autotune and args.precision != "f32" and not (args.tiles_file and "f32" not in tiles):
+        if not args.no_autotune and not args.no_graph and args.precision != "f32" and not (tiles_loaded and "f32" not in tiles):
             if "f32" not in tiles:
                 plan.autotune(verbose=False, splits=splits, concurrent=1, precisions=(0,))
                 tiles["f32"] = plan.export_tiles()
@@ -417,7 +420,24 @@ def main(argv=None):
         flops_bf = sum(st.flops for st, pr in zip(plan.conv_steps, precs) if pr == 1)
         ideal_ms = sum(st.flops / ((BF16X3_PEAK_TFLOPS if pr == 1 else F32_MFMA_PEAK_TFLOPS) * 1e12) * 1e3
                        for st, pr in zip(plan.conv_steps, precs))
-        serial_server = InFlightDetector(model, x, depth=1, tiles=tiles["serial"])
+        if args.no_graph:
+            n_fly = 1
+
+            class _Eager:                                   # the serial schedule as plain launches (profiling aid)
+                _next = 0
+
+                def submit(self, after=None):
+                    outs = model(x)
+                    det = hip_ops.detections(outs[0], outs[1], outs[2])
+                    if after is not None:
+                        after(tuple(outs) + (det,))
+                    self._next += 1
+
+                def drain(self):
+                    torch.cuda.synchronize()
+            serial_server = _Eager()
+        else:
+            serial_server = InFlightDetector(model, x, depth=1, tiles=tiles["serial"])
         serial = timer.measure(make_step(serial_server, 1), args.steps, args.warmup, args.repeats)
         serial_server.drain()
         # ---- schedule 2: --in-flight steps overlapped on as many streams (the default headline)
@@ -468,7 +488,7 @@ def main(argv=None):
                                    f"3x{args.height}x{args.width}, {args.num_classes}+1 classes, 3000->300 proposals"
                                    + (" (BASELINE configs[4]: data-parallel, 8 images per rank)" if world > 1 and B == 8 else ""),
                        "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}",
-                       "hip_graph": True, "autotuned_tiles": not args.no_autotune, "steps_in_flight": n_fly,
+                       "hip_graph": not args.no_graph, "autotuned_tiles": not args.no_autotune, "steps_in_flight": n_fly,
                        "collective": None if n_gpus == 1 else f"all_gather_into_tensor [{n_gpus * B},300,6] f32 ({args.dist_backend})"},
             "repeats": {"n": head["n"], "steps_each": head["steps"], "ms_per_step_median": round(head["ms_per_step"], 4),
                         "ms_per_step_min": round(head["min"], 4), "ms_per_step_max": round(head["max"], 4)},

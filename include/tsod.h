@@ -18,6 +18,10 @@
  *     pitch P and channel offset O lives at ((n*H + h)*W + w)*P + O + c.  Pitch/offset let a
  *     conv read or write a channel slice of a wider buffer (HarDNet's concat is free).
  *   - boxes are xyxy pixel coordinates, f32.
+ *   - there is NO collective here: the one exchange of the data-parallel job (an all-gather of [B,300,6] detection
+ *     records per step) is issued through torch.distributed (backend "nccl" = RCCL over xGMI), which owns the
+ *     communicator; SURVEY 8(b)'s thin `tsod_allgather_f32` wrapper over ncclAllGather was dropped on purpose
+ *     (two_stage_object_detection_amd/dist.py).
  */
 #ifndef TSOD_H
 #define TSOD_H
