@@ -245,6 +245,18 @@ int tsod_roi_pool_avg_f32(const float *feat, int32_t B, int32_t Hf, int32_t Wf, 
                           float spatial_scale, int32_t PH, int32_t PW, float *out, int32_t out_pitch,
                           tsod_stream_t stream);
 
+/* RoIAlign: the added `roi_op="align"` option of the head (the reference builds RoIPool).  Semantics of
+ * torchvision.ops.roi_align(input, rois5, (PH,PW), spatial_scale, sampling_ratio, aligned): bilinear samples on a
+ * sampling_ratio x sampling_ratio grid per bin (0 = adaptive: ceil(roi extent / P)), averaged; layouts as tsod_roi_pool_f32.
+ * tsod_roi_align_avg_f32 is the fused form of tsod_roi_pool_avg_f32 (RoI rescale + index + align + mean over the bins). */
+int tsod_roi_align_f32(const float *feat, int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t feat_pitch,
+                       const float *rois5, int32_t K, float spatial_scale, int32_t PH, int32_t PW, int32_t sampling_ratio,
+                       int32_t aligned, float *out, tsod_stream_t stream);
+int tsod_roi_align_avg_f32(const float *feat, int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t feat_pitch,
+                           const float *rois, const int32_t *roi_indices, int32_t R, float img_h, float img_w,
+                           float spatial_scale, int32_t PH, int32_t PW, int32_t sampling_ratio, int32_t aligned,
+                           float *out, int32_t out_pitch, tsod_stream_t stream);
+
 /* Final detection records (nets/frcnn_training.py:311-319): per RoI the arg-max class
  * over all n_class logits (first max wins), its raw logit, and loc2bbox(roi, loc of that class).
  *   cls_locs [K] rows of 4*n_class floats (row pitch loc_pitch), scores [K] rows of n_class (pitch score_pitch) - both may

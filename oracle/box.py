@@ -41,6 +41,8 @@ def _lib():
         lib.oracle_nms_pad.restype = i64
         lib.oracle_roi_pool.argtypes = [p, i64, i64, i64, i64, p, i64, f32, i64, i64, p]
         lib.oracle_roi_pool.restype = ctypes.c_int
+        lib.oracle_roi_align.argtypes = [p, i64, i64, i64, i64, p, i64, f32, i64, i64, i64, ctypes.c_int, p]
+        lib.oracle_roi_align.restype = ctypes.c_int
         lib.oracle_bbox_iou.argtypes = [p, i64, p, i64, f32, p]
         lib.oracle_bbox_iou.restype = None
         _LIB = lib
@@ -167,6 +169,21 @@ def roi_pool(x: torch.Tensor, rois: torch.Tensor, output_size=(7, 7), spatial_sc
     return out
 
 
+def roi_align(x: torch.Tensor, rois: torch.Tensor, output_size=(7, 7), spatial_scale: float = 1.0, sampling_ratio: int = 2,
+              aligned: bool = False) -> torch.Tensor:
+    """torchvision.ops.roi_align(x, rois, output_size, spatial_scale, sampling_ratio, aligned) (C restatement of the
+    published CPU kernel, PARITY UNPINNED; checker of the added roi_op="align" option - the reference uses RoIPool)."""
+    xc, rc = _f32c(x), _f32c(rois)
+    B, C, H, W = xc.shape
+    K = rc.shape[0]
+    PH, PW = output_size
+    out = torch.empty((K, C, PH, PW), dtype=torch.float32)
+    if _lib().oracle_roi_align(xc.data_ptr(), B, C, H, W, rc.data_ptr(), K, float(spatial_scale), PH, PW,
+                               int(sampling_ratio), 1 if aligned else 0, out.data_ptr()) != 0:
+        raise IndexError("roi batch index out of range")
+    return out
+
+
 def roi_pool_python(x, rois, output_size=(7, 7), spatial_scale=1.0):
     """Pure-Python loop version of ``roi_pool`` (small cases only) to cross-check the C code."""
     x = np.asarray(x, dtype=np.float32)
@@ -272,7 +289,7 @@ def rpn_forward(sd, feat, img_size, scale=1.0, feat_stride=16, mode="training",
     return out
 
 
-def roi_head_forward(sd, feat, rois, roi_indices, img_size, roi_size=7, spatial_scale=1.0, prefix=""):
+def roi_head_forward(sd, feat, rois, roi_indices, img_size, roi_size=7, spatial_scale=1.0, prefix="", roi_op="pool"):
     """HarNetRoIHead.forward, nets/classify.py:19-56, with the classifier of
     models/hardnet.py:203-212 (mean over the 7x7 bins) inlined.
 
@@ -286,7 +303,10 @@ def roi_head_forward(sd, feat, rois, roi_indices, img_size, roi_size=7, spatial_
     fm[:, [0, 2]] = flat[:, [0, 2]] / img_size[1] * wf
     fm[:, [1, 3]] = flat[:, [1, 3]] / img_size[0] * hf
     idx = roi_indices.reshape(-1, 1).to(fm.dtype).repeat_interleave(R, dim=0)
-    pooled = roi_pool(feat, torch.cat([idx, fm], dim=1), (roi_size, roi_size), spatial_scale)
+    if roi_op == "align":      # the added option (RoIAlign, sampling_ratio 2, aligned=False); the reference's head is "pool"
+        pooled = roi_align(feat, torch.cat([idx, fm], dim=1), (roi_size, roi_size), spatial_scale, 2, False)
+    else:
+        pooled = roi_pool(feat, torch.cat([idx, fm], dim=1), (roi_size, roi_size), spatial_scale)
     fc7 = F.adaptive_avg_pool2d(pooled, (1, 1)).flatten(1)
     cls_locs = F.linear(fc7, sd[prefix + "cls_loc.weight"], sd[prefix + "cls_loc.bias"])
     scores = F.linear(fc7, sd[prefix + "score.weight"], sd[prefix + "score.bias"])

@@ -182,6 +182,64 @@ int oracle_roi_pool(const float *x, int64_t B, int64_t C, int64_t H, int64_t W,
     return 0;
 }
 
+/*
+ * torchvision.ops.roi_align(x[B,C,H,W], rois[K,5], (PH,PW), spatial_scale, sampling_ratio, aligned) -> [K,C,PH,PW].
+ * Restated from the published torchvision CPU kernel (ops/cpu/roi_align_kernel.cpp + roi_align_common.h,
+ * pre_calc_for_bilinear_interpolate).  PARITY UNPINNED: torchvision is absent from /root/reference and from the image and
+ * the reference itself uses RoIPool (nets/classify.py:17); this is the checker of the ADDED roi_op="align" option only.
+ */
+int oracle_roi_align(const float *x, int64_t B, int64_t C, int64_t H, int64_t W, const float *rois, int64_t K,
+                     float spatial_scale, int64_t PH, int64_t PW, int64_t sampling_ratio, int aligned, float *out)
+{
+    for (int64_t k = 0; k < K; ++k) {
+        const float *r = rois + 5 * k;
+        int64_t b = (int64_t)r[0];
+        if (b < 0 || b >= B) return -1;
+        float offset = aligned ? 0.5f : 0.f;
+        float roi_start_w = r[1] * spatial_scale - offset;
+        float roi_start_h = r[2] * spatial_scale - offset;
+        float roi_end_w = r[3] * spatial_scale - offset;
+        float roi_end_h = r[4] * spatial_scale - offset;
+        float roi_width = roi_end_w - roi_start_w;
+        float roi_height = roi_end_h - roi_start_h;
+        if (!aligned) {
+            if (roi_width < 1.f) roi_width = 1.f;
+            if (roi_height < 1.f) roi_height = 1.f;
+        }
+        float bin_size_h = roi_height / (float)PH;
+        float bin_size_w = roi_width / (float)PW;
+        int grid_h = sampling_ratio > 0 ? (int)sampling_ratio : (int)ceilf(roi_height / (float)PH);
+        int grid_w = sampling_ratio > 0 ? (int)sampling_ratio : (int)ceilf(roi_width / (float)PW);
+        float count = (float)(grid_h * grid_w > 1 ? grid_h * grid_w : 1);
+        for (int64_t c = 0; c < C; ++c) {
+            const float *plane = x + ((b * C + c) * H) * W;
+            for (int64_t ph = 0; ph < PH; ++ph)
+                for (int64_t pw = 0; pw < PW; ++pw) {
+                    float acc = 0.f;
+                    for (int iy = 0; iy < grid_h; ++iy) {
+                        float yy = roi_start_h + (float)ph * bin_size_h + ((float)iy + .5f) * bin_size_h / (float)grid_h;
+                        for (int ix = 0; ix < grid_w; ++ix) {
+                            float xx = roi_start_w + (float)pw * bin_size_w + ((float)ix + .5f) * bin_size_w / (float)grid_w;
+                            float yv = yy, xv = xx;
+                            if (yv < -1.f || yv > (float)H || xv < -1.f || xv > (float)W) continue;
+                            if (yv <= 0.f) yv = 0.f;
+                            if (xv <= 0.f) xv = 0.f;
+                            int y_low = (int)yv, x_low = (int)xv, y_high, x_high;
+                            if (y_low >= (int)H - 1) { y_high = y_low = (int)H - 1; yv = (float)y_low; } else y_high = y_low + 1;
+                            if (x_low >= (int)W - 1) { x_high = x_low = (int)W - 1; xv = (float)x_low; } else x_high = x_low + 1;
+                            float ly = yv - (float)y_low, lx = xv - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+                            float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                            acc += w1 * plane[(int64_t)y_low * W + x_low] + w2 * plane[(int64_t)y_low * W + x_high] +
+                                   w3 * plane[(int64_t)y_high * W + x_low] + w4 * plane[(int64_t)y_high * W + x_high];
+                        }
+                    }
+                    out[((k * C + c) * PH + ph) * PW + pw] = acc / count;
+                }
+        }
+    }
+    return 0;
+}
+
 /* bbox_iou (/root/reference/utils/loc_bbox_iou.py:4-27): dense [Na,Nb], +eps in the denominator. */
 void oracle_bbox_iou(const float *a, int64_t na, const float *b, int64_t nb, float eps, float *out)
 {

@@ -30,7 +30,7 @@ def extractor_forward(sd, x, backbone="resnet50", prefix="extractor."):
 
 @torch.inference_mode()
 def detector_forward(sd, x, backbone="resnet50", scale=1.0, mode="training",
-                     ratios=(0.5, 1, 2), anchor_scales=(8, 16, 32), return_debug=False):
+                     ratios=(0.5, 1, 2), anchor_scales=(8, 16, 32), return_debug=False, roi_op="pool"):
     """FasterRCNN.forward(x, scale, mode="forward") (nets/frcnn.py:30-40) ->
     (roi_cls_locs [B,R,4*n_class], roi_scores [B,R,n_class], rois [B,R,4], roi_indices [B])."""
     stride, _ = BACKBONES[backbone]
@@ -42,7 +42,7 @@ def detector_forward(sd, x, backbone="resnet50", scale=1.0, mode="training",
         rpn, dbg = rpn
     rpn_locs, rpn_scores, rois, anchor = rpn
     roi_indices = torch.arange(x.shape[0], dtype=torch.int32)
-    cls_locs, scores = roi_head_forward(sd, feat, rois, roi_indices, tuple(x.shape[2:]), prefix="head.")
+    cls_locs, scores = roi_head_forward(sd, feat, rois, roi_indices, tuple(x.shape[2:]), prefix="head.", roi_op=roi_op)
     out = (cls_locs, scores, rois, roi_indices)
     if return_debug:
         dbg = dict(dbg, feat=feat, rpn_locs=rpn_locs, rpn_scores=rpn_scores, anchor=anchor)

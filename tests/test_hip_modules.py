@@ -520,3 +520,31 @@ def test_retuning_a_plan_keeps_earlier_graphs_valid(dev, synth):
         for a, b in zip(ref[:3], outs[:3]):
             assert torch.equal(a, b)
         model.extractor.drop_plan(slot=5)
+
+
+@pytest.mark.parametrize("backbone,shape", [("resnet50", (2, 3, 320, 448)), ("resnet50", (1, 3, 800, 1333)), ("hardnet39", (1, 3, 320, 448))])
+def test_detector_with_roi_align_head(dev, backbone, shape):
+    """The added ``roi_op="align"`` (the north star's RoIAlign wording): same detector, the head pooling RoIs
+    with torchvision-style RoIAlign (sampling_ratio 2, aligned=False) instead of the reference's RoIPool; checked against
+    the oracle built the same way.  Same state_dict keys as the default head (RoIAlign has no parameters)."""
+    from two_stage_object_detection_amd.nets.frcnn import FasterRCNN
+    from two_stage_object_detection_amd.testing import compare_detector_outputs, synthetic_detector
+    base, sd = synthetic_detector(backbone, num_classes=20, seed=0)
+    if backbone.startswith("hardnet"):
+        oracle.calibrate_bn(sd, _img((2, 3, 256, 320), seed=99), oracle.hardnet_trunk, arch=int(backbone[-2:]), prefix="extractor.")
+    model = FasterRCNN(20, backbone=backbone, roi_op="align").eval()
+    assert list(model.state_dict().keys()) == list(base.state_dict().keys())
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    x = _img(shape)
+    with torch.inference_mode():
+        ref = oracle.detector_forward(sd, x, backbone=backbone, roi_op="align")
+        ref_pool = oracle.detector_forward(sd, x, backbone=backbone)
+        got = [o.cpu() for o in model(x.to(dev))]
+        model.raise_if_error()
+    rep = compare_detector_outputs(got, ref)
+    print("roi_align", backbone, shape, rep)
+    assert rep["ok"] and rep["rows_unmatched"] == 0 and rep["class_mismatch"] == 0, rep
+    assert (ref[1] - ref_pool[1]).abs().max().item() > 1e-3            # it really is a different pooling
+    with pytest.raises(ValueError):
+        FasterRCNN(20, backbone=backbone, roi_op="bilinear")

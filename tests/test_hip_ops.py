@@ -444,3 +444,36 @@ def test_utils_anchor_functions_match_the_references_vectors(dev, golden_dir):
     assert full.shape == (37800, 4)
     assert np.array_equal(full[[0, 9, 755, 756, 37799]].numpy(), z["shifted_s16_h50_w84_rows"])
     assert torch.equal(full, oracle.enumerate_shifted_anchor(base.cpu(), 16, 50, 84))
+
+
+# ----------------------------------------------------------------------------- RoIAlign (added roi_op="align"; parity unpinned)
+@pytest.mark.parametrize("C,Hf,Wf,sampling_ratio,aligned", [(512, 50, 84, 2, False), (2048, 25, 42, 0, False), (8, 6, 6, 2, True),
+                                                          (64, 13, 17, 3, True)])
+def test_roi_align_matches_oracle(ops, dev, C, Hf, Wf, sampling_ratio, aligned):
+    g = torch.Generator().manual_seed(23)
+    B, K = 2, 48
+    feat = torch.randn(B, C, Hf, Wf, generator=g)
+    r = _rand_boxes(g, K, span=float(Wf), wh=float(Wf) * 0.5) - 2.0
+    r[0] = torch.tensor([-30., -30, -20, -20])                  # entirely outside: samples nothing
+    r[1] = torch.tensor([0.2, 0.3, 0.25, 0.31])                 # tiny: extents floored at 1 unless aligned
+    rois5 = torch.cat([torch.randint(0, B, (K, 1), generator=g).float(), r], dim=1)
+    ref = oracle.roi_align(feat, rois5, (7, 7), 0.75, sampling_ratio, aligned)
+    got = ops.roi_align_nhwc(ops.nchw_to_nhwc(feat.to(dev)), rois5.to(dev), (7, 7), 0.75, sampling_ratio, aligned).cpu()
+    assert (got - ref).abs().max().item() <= 1e-5               # same f32 expression order; in practice bit-equal or 1 ulp
+    assert (got[0] == 0).all()
+
+
+def test_roi_align_avg_fused(ops, dev):
+    g = torch.Generator().manual_seed(24)
+    B, R, C, Hf, Wf, H, W = 2, 300, 2048, 25, 42, 800, 1333
+    feat = torch.randn(B, C, Hf, Wf, generator=g)
+    rois = torch.stack([_rand_boxes(g, R, span=900.0, wh=400.0) for _ in range(B)])
+    idx = torch.tensor([1, 0], dtype=torch.int32)
+    flat = rois.view(-1, 4)
+    fm = torch.zeros_like(flat)
+    fm[:, [0, 2]] = flat[:, [0, 2]] / W * Wf
+    fm[:, [1, 3]] = flat[:, [1, 3]] / H * Hf
+    rois5 = torch.cat([idx.float().repeat_interleave(R).view(-1, 1), fm], dim=1)
+    ref = F.adaptive_avg_pool2d(oracle.roi_align(feat, rois5, (7, 7), 1.0, 2, False), 1).flatten(1)
+    got = ops.roi_align_avg_nhwc(ops.nchw_to_nhwc(feat.to(dev)), rois.to(dev), idx.to(dev), H, W).cpu()
+    assert (got - ref).abs().max().item() < 1e-5

@@ -143,3 +143,77 @@ def test_postprocess_per_class_equals_one_nms_per_class():
     out0 = oracle.postprocess(det, 0.3)[0]
     keep0 = nms_python(det[0, :, :4].numpy(), det[0, :, 4].numpy(), 0.3)
     assert torch.equal(out0, det[0][keep0])
+
+
+# ----------------------------------------------------------------------------- roi_align (added option; parity unpinned)
+def _roi_align_python(x, rois, out_size, scale, sampling_ratio, aligned):
+    """Independent pure-Python restatement of torchvision.ops.roi_align's published definition (bilinear samples on a
+    regular grid per bin, averaged) in float64 - small cases only - to cross-check the C code's structure."""
+    import math
+    x = np.asarray(x, dtype=np.float64)
+    K, (PH, PW) = len(rois), out_size
+    _, C, H, W = x.shape
+    out = np.zeros((K, C, PH, PW))
+
+    def bil(plane, y, xx):
+        if y < -1 or y > H or xx < -1 or xx > W:
+            return 0.0
+        y, xx = max(y, 0.0), max(xx, 0.0)
+        yl, xl = int(y), int(xx)
+        if yl >= H - 1:
+            yh = yl = H - 1; y = float(yl)
+        else:
+            yh = yl + 1
+        if xl >= W - 1:
+            xh = xl = W - 1; xx = float(xl)
+        else:
+            xh = xl + 1
+        ly, lx = y - yl, xx - xl
+        return (1 - ly) * (1 - lx) * plane[yl, xl] + (1 - ly) * lx * plane[yl, xh] + ly * (1 - lx) * plane[yh, xl] + ly * lx * plane[yh, xh]
+    for k, r in enumerate(np.asarray(rois, dtype=np.float64)):
+        b = int(r[0])
+        off = 0.5 if aligned else 0.0
+        sw, sh, ew, eh = r[1] * scale - off, r[2] * scale - off, r[3] * scale - off, r[4] * scale - off
+        rw, rh = ew - sw, eh - sh
+        if not aligned:
+            rw, rh = max(rw, 1.0), max(rh, 1.0)
+        bh, bw = rh / PH, rw / PW
+        gh = sampling_ratio if sampling_ratio > 0 else math.ceil(rh / PH)
+        gw = sampling_ratio if sampling_ratio > 0 else math.ceil(rw / PW)
+        cnt = max(gh * gw, 1)
+        for c in range(C):
+            for ph in range(PH):
+                for pw in range(PW):
+                    acc = 0.0
+                    for iy in range(gh):
+                        for ix in range(gw):
+                            acc += bil(x[b, c], sh + ph * bh + (iy + .5) * bh / gh, sw + pw * bw + (ix + .5) * bw / gw)
+                    out[k, c, ph, pw] = acc / cnt
+    return out
+
+
+@pytest.mark.parametrize("sampling_ratio,aligned", [(2, False), (0, False), (2, True), (3, True)])
+def test_roi_align_c_matches_python_definition(sampling_ratio, aligned):
+    g = torch.Generator().manual_seed(40 + sampling_ratio)
+    x = torch.randn(2, 3, 9, 11, generator=g)
+    rois = torch.tensor([[0, 1.2, 0.7, 7.9, 6.4], [1, -3.0, -2.0, 4.0, 3.0], [0, 8.5, 6.0, 14.0, 12.0], [1, 2.0, 2.0, 2.2, 2.1],
+                         [0, 0.0, 0.0, 10.0, 8.0], [1, 30.0, 30.0, 40.0, 40.0]])
+    got = oracle.roi_align(x, rois, (3, 4), 0.9, sampling_ratio, aligned)
+    ref = _roi_align_python(x.numpy(), rois.numpy(), (3, 4), 0.9, sampling_ratio, aligned)
+    assert np.abs(got.numpy() - ref).max() < 1e-5
+    assert (got[5] == 0).all()                                    # an RoI entirely outside the map samples nothing
+
+
+def test_roi_align_known_answers():
+    """Hand-derived: on a linear ramp f(y, x) = 10 y + x bilinear sampling is exact, so every bin's value is the ramp at the
+    bin centre; a 1x1 output over the whole map is the map's mean of the sampled points."""
+    H, W = 6, 8
+    ramp = (10.0 * torch.arange(H).view(H, 1) + torch.arange(W).view(1, W)).view(1, 1, H, W).float()
+    rois = torch.tensor([[0, 1.0, 1.0, 5.0, 4.0]])
+    out = oracle.roi_align(ramp, rois, (3, 2), 1.0, 2, False)[0, 0]
+    # bins: height 3 / 3 = 1 starting at y = 1, width 4 / 2 = 2 starting at x = 1 -> centres (1.5 + ph, 2 + 2 pw)
+    ref = torch.tensor([[10 * (1.5 + ph) + (2.0 + 2 * pw) for pw in range(2)] for ph in range(3)])
+    assert torch.allclose(out, ref, atol=1e-5)
+    const = torch.full((1, 2, 5, 5), 3.25)
+    assert torch.allclose(oracle.roi_align(const, torch.tensor([[0, 0.3, 0.4, 3.7, 4.1]]), (7, 7), 1.0, 0, True),
+                          torch.full((1, 2, 7, 7), 3.25))

@@ -79,6 +79,11 @@ _SIGNATURES = {
                                   c_int32, c_int32, c_void_p, c_void_p]),
     "tsod_roi_pool_avg_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
                                       c_float, c_float, c_float, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "tsod_roi_align_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_float,
+                                   c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "tsod_roi_align_avg_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                       c_float, c_float, c_float, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32,
+                                       c_void_p]),
     "tsod_detections_f32": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "tsod_resize_aa_taps": (c_int32, [c_int32, c_int32]),
     "tsod_resize_aa_tables_f32": (c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -140,7 +140,158 @@ roi_pool_avg_kernel(const float *__restrict__ feat, int B, int Hf, int Wf, int C
             make_float4(total.x / nb, total.y / nb, total.z / nb, total.w / nb);
 }
 
+// ---- RoIAlign (the north star's wording; the reference's head is built with RoIPool, nets/classify.py:17, so this is the
+// added `roi_op="align"` option of SURVEY 8(b)).  Algorithm = torchvision.ops.roi_align (ops/cpu/roi_align_kernel.cpp +
+// roi_align_common.h), restated in oracle/box_ops.c: PARITY UNPINNED like RoIPool (torchvision is not in the image).
+//   offset = aligned ? 0.5 : 0; start = coord * scale - offset; extent = end - start (>= 1 unless aligned);
+//   bin = extent / P; grid = sampling_ratio > 0 ? sampling_ratio : ceil(extent / P); count = max(grid_h * grid_w, 1)
+//   sample (iy, ix) of bin (ph, pw): y = start_h + ph * bin_h + (iy + .5) * bin_h / grid_h (x likewise);
+//   outside [-1, H] x [-1, W] -> 0; clamp at 0; low = (int), high = low + 1 (both H-1 at the border, y = low there);
+//   value = hy*hx*v1 + hy*lx*v2 + ly*hx*v3 + ly*lx*v4; bin output = sum over the grid (iy outer, ix inner) / count.
+struct AlignGeom {
+    int b, grid_h, grid_w;
+    float start_h, start_w, bin_h, bin_w, count;
+};
+
+__device__ __forceinline__ AlignGeom align_geom(float bidx, float x1, float y1, float x2, float y2, float scale, int PH,
+                                                int PW, int sampling_ratio, int aligned) {
+    AlignGeom g;
+    g.b = (int)bidx;
+    const float offset = aligned ? 0.5f : 0.f;
+    g.start_w = x1 * scale - offset;
+    g.start_h = y1 * scale - offset;
+    const float end_w = x2 * scale - offset, end_h = y2 * scale - offset;
+    float rw = end_w - g.start_w, rh = end_h - g.start_h;
+    if (!aligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
+    g.bin_h = rh / (float)PH;
+    g.bin_w = rw / (float)PW;
+    g.grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+    g.grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+    g.count = (float)max(g.grid_h * g.grid_w, 1);
+    return g;
+}
+
+// sum of the grid samples of bin (ph, pw) for one channel quad (not yet divided by count)
+__device__ __forceinline__ float4 align_bin_sum(const float *__restrict__ fmap, int Hf, int Wf, int pitch, int c4,
+                                                const AlignGeom &g, int ph, int pw) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int iy = 0; iy < g.grid_h; ++iy) {
+        const float yy = g.start_h + (float)ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+        for (int ix = 0; ix < g.grid_w; ++ix) {
+            const float xx = g.start_w + (float)pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+            float y = yy, x = xx;
+            if (y < -1.f || y > (float)Hf || x < -1.f || x > (float)Wf) continue;      // contributes 0
+            if (y <= 0.f) y = 0.f;
+            if (x <= 0.f) x = 0.f;
+            int y_low = (int)y, x_low = (int)x, y_high, x_high;
+            if (y_low >= Hf - 1) { y_high = y_low = Hf - 1; y = (float)y_low; } else y_high = y_low + 1;
+            if (x_low >= Wf - 1) { x_high = x_low = Wf - 1; x = (float)x_low; } else x_high = x_low + 1;
+            const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+            const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+            const float4 v1 = *reinterpret_cast<const float4 *>(fmap + ((long)y_low * Wf + x_low) * pitch + 4 * c4);
+            const float4 v2 = *reinterpret_cast<const float4 *>(fmap + ((long)y_low * Wf + x_high) * pitch + 4 * c4);
+            const float4 v3 = *reinterpret_cast<const float4 *>(fmap + ((long)y_high * Wf + x_low) * pitch + 4 * c4);
+            const float4 v4 = *reinterpret_cast<const float4 *>(fmap + ((long)y_high * Wf + x_high) * pitch + 4 * c4);
+            acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+            acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+            acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+            acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+        }
+    }
+    return acc;
+}
+
+// out [K][C][PH][PW] (torchvision's layout): thread = (channel quad, bin)
+__global__ void __launch_bounds__(256)
+roi_align_kernel(const float *__restrict__ feat, int B, int Hf, int Wf, int C, int pitch, const float *__restrict__ rois5,
+                 float scale, int PH, int PW, int sampling_ratio, int aligned, float *__restrict__ out) {
+    const int k = blockIdx.x;
+    const float *r = rois5 + 5l * k;
+    const AlignGeom g = align_geom(r[0], r[1], r[2], r[3], r[4], scale, PH, PW, sampling_ratio, aligned);
+    if (g.b < 0 || g.b >= B) return;
+    const float *fmap = feat + (long)g.b * Hf * Wf * pitch;
+    const int bins = PH * PW, quads = C >> 2;
+    for (int t = threadIdx.x; t < quads * bins; t += blockDim.x) {
+        const int c4 = t % quads, bin = t / quads;                   // lanes over channel quads: coalesced sample reads
+        const float4 sum = align_bin_sum(fmap, Hf, Wf, pitch, c4, g, bin / PW, bin % PW);
+        float *o = out + ((long)k * C + 4 * c4) * bins + bin;
+        o[0] = sum.x / g.count; o[bins] = sum.y / g.count; o[2 * bins] = sum.z / g.count; o[3 * bins] = sum.w / g.count;
+    }
+}
+
+// fused with the RoI rescale (nets/classify.py:29-38) and the classifier's mean over the PH*PW bins: out [B*R][out_pitch]
+__global__ void __launch_bounds__(256)
+roi_align_avg_kernel(const float *__restrict__ feat, int B, int Hf, int Wf, int C, int pitch, const float *__restrict__ rois,
+                     const int *__restrict__ roi_indices, int R, float img_h, float img_w, float scale, int PH, int PW,
+                     int sampling_ratio, int aligned, float *__restrict__ out, int out_pitch) {
+    __shared__ float4 rowsum[8][kQuads];
+    const int k = blockIdx.x;
+    const float4 rr = reinterpret_cast<const float4 *>(rois)[k];
+    const float fx1 = rr.x / img_w * (float)Wf, fy1 = rr.y / img_h * (float)Hf;
+    const float fx2 = rr.z / img_w * (float)Wf, fy2 = rr.w / img_h * (float)Hf;
+    const AlignGeom g = align_geom((float)roi_indices[k / R], fx1, fy1, fx2, fy2, scale, PH, PW, sampling_ratio, aligned);
+    if (g.b < 0 || g.b >= B) return;
+    const float *fmap = feat + (long)g.b * Hf * Wf * pitch;
+    const float nb = (float)(PH * PW);
+    const int q = threadIdx.x % kQuads, slot = threadIdx.x / kQuads;
+    const int c4 = blockIdx.y * kQuads + q;
+    const bool live = c4 < (C >> 2);
+    float4 total = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ph0 = 0; ph0 < PH; ph0 += 8) {
+        const int ph = ph0 + slot;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live && ph < PH) {
+            for (int pw = 0; pw < PW; ++pw) {
+                const float4 s4 = align_bin_sum(fmap, Hf, Wf, pitch, c4, g, ph, pw);
+                acc.x += s4.x / g.count; acc.y += s4.y / g.count; acc.z += s4.z / g.count; acc.w += s4.w / g.count;
+            }
+        }
+        rowsum[slot][q] = acc;
+        __syncthreads();
+        if (slot == 0) {
+            const int rows = min(8, PH - ph0);
+            for (int r = 0; r < rows; ++r) {
+                const float4 v = rowsum[r][q];
+                total.x += v.x; total.y += v.y; total.z += v.z; total.w += v.w;
+            }
+        }
+        __syncthreads();
+    }
+    if (slot == 0 && live)
+        *reinterpret_cast<float4 *>(out + (long)k * out_pitch + 4 * c4) =
+            make_float4(total.x / nb, total.y / nb, total.z / nb, total.w / nb);
+}
+
 }  // namespace
+
+extern "C" int tsod_roi_align_f32(const float *feat, int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t feat_pitch,
+                                  const float *rois5, int32_t K, float spatial_scale, int32_t PH, int32_t PW,
+                                  int32_t sampling_ratio, int32_t aligned, float *out, tsod_stream_t stream) {
+    TSOD_REQUIRE(feat && rois5 && out, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(B > 0 && Hf > 0 && Wf > 0 && C > 0 && K > 0 && PH > 0 && PW > 0 && sampling_ratio >= 0, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE((C & 3) == 0 && (feat_pitch & 3) == 0 && feat_pitch >= C && tsod_aligned16(feat), TSOD_ERR_ALIGNMENT);
+    hipLaunchKernelGGL(roi_align_kernel, dim3(K), dim3(256), 0, tsod_stream(stream), feat, B, Hf, Wf, C, feat_pitch, rois5,
+                       spatial_scale, PH, PW, sampling_ratio, aligned ? 1 : 0, out);
+    return tsod_launch_status();
+}
+
+extern "C" int tsod_roi_align_avg_f32(const float *feat, int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t feat_pitch,
+                                      const float *rois, const int32_t *roi_indices, int32_t R, float img_h, float img_w,
+                                      float spatial_scale, int32_t PH, int32_t PW, int32_t sampling_ratio, int32_t aligned,
+                                      float *out, int32_t out_pitch, tsod_stream_t stream) {
+    TSOD_REQUIRE(feat && rois && roi_indices && out, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(B > 0 && Hf > 0 && Wf > 0 && C > 0 && R > 0 && PH > 0 && PW > 0 && PH <= 64 && sampling_ratio >= 0,
+                 TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(img_h > 0.f && img_w > 0.f, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE((C & 3) == 0 && (feat_pitch & 3) == 0 && feat_pitch >= C && (out_pitch & 3) == 0 && out_pitch >= C,
+                 TSOD_ERR_ALIGNMENT);
+    TSOD_REQUIRE(tsod_aligned16(feat) && tsod_aligned16(rois) && tsod_aligned16(out), TSOD_ERR_ALIGNMENT);
+    const int quads = C / 4;
+    hipLaunchKernelGGL(roi_align_avg_kernel, dim3(B * R, (quads + kQuads - 1) / kQuads), dim3(256), 0, tsod_stream(stream),
+                       feat, B, Hf, Wf, C, feat_pitch, rois, roi_indices, R, img_h, img_w, spatial_scale, PH, PW,
+                       sampling_ratio, aligned ? 1 : 0, out, out_pitch);
+    return tsod_launch_status();
+}
 
 extern "C" int tsod_roi_pool_f32(const float *feat, int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t feat_pitch,
                                  const float *rois5, int32_t K, float spatial_scale, int32_t PH, int32_t PW,

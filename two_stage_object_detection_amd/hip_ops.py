@@ -360,6 +360,34 @@ def _row_pitch(t: torch.Tensor, width: int) -> int | None:
     return t.stride(1)
 
 
+def roi_align_nhwc(feat: torch.Tensor, rois5: torch.Tensor, output_size=(7, 7), spatial_scale=1.0, sampling_ratio=2,
+                   aligned=False) -> torch.Tensor:
+    """feat [B,Hf,Wf,C] NHWC, rois5 [K,5] -> [K,C,PH,PW] (torchvision.ops.roi_align semantics and layout)."""
+    require_cuda(feat, "roi_align")
+    B, Hf, Wf, C = feat.shape
+    K = rois5.shape[0]
+    PH, PW = output_size
+    out = torch.empty((K, C, PH, PW), dtype=torch.float32, device=feat.device)
+    check(lib().tsod_roi_align_f32(ptr(feat), B, Hf, Wf, C, C, ptr(rois5.contiguous()), K, float(spatial_scale), PH, PW,
+                                   int(sampling_ratio), 1 if aligned else 0, ptr(out), stream_ptr()), "roi_align")
+    return out
+
+
+def roi_align_avg_nhwc(feat: torch.Tensor, rois: torch.Tensor, roi_indices: torch.Tensor, img_h, img_w, output_size=(7, 7),
+                       spatial_scale=1.0, sampling_ratio=2, aligned=False) -> torch.Tensor:
+    """feat [B,Hf,Wf,C], rois [B,R,4] image coords, roi_indices [B] i32 -> [B*R, C] (rescale + RoIAlign + mean over bins)."""
+    require_cuda(feat, "roi_align_avg")
+    B, Hf, Wf, C = feat.shape
+    R = rois.shape[1]
+    PH, PW = output_size
+    out = torch.empty((rois.shape[0] * R, C), dtype=torch.float32, device=feat.device)
+    check(lib().tsod_roi_align_avg_f32(ptr(feat), B, Hf, Wf, C, C, ptr(rois.contiguous()),
+                                       ptr(roi_indices.to(torch.int32).contiguous()), R, float(img_h), float(img_w),
+                                       float(spatial_scale), PH, PW, int(sampling_ratio), 1 if aligned else 0, ptr(out), C,
+                                       stream_ptr()), "roi_align_avg")
+    return out
+
+
 def detections(cls_locs: torch.Tensor, scores: torch.Tensor, rois: torch.Tensor) -> torch.Tensor:
     """[B,R,4*n_class], [B,R,n_class], [B,R,4] -> [B,R,6] (x1,y1,x2,y2,score,class)."""
     require_cuda(scores, "detections")

@@ -30,13 +30,35 @@ class RoIPool(nn.Module):
         return hip_ops.roi_pool_nhwc(hip_ops.nchw_to_nhwc(x), rois, self.output_size, self.spatial_scale)
 
 
+class RoIAlign(nn.Module):
+    """Stand-in for torchvision.ops.RoIAlign (same ctor; NCHW in, [K,C,PH,PW] out) on the HIP kernel."""
+
+    def __init__(self, output_size, spatial_scale, sampling_ratio, aligned=False):
+        super().__init__()
+        self.output_size = tuple(output_size) if isinstance(output_size, (tuple, list)) else (output_size, output_size)
+        self.spatial_scale, self.sampling_ratio, self.aligned = spatial_scale, sampling_ratio, aligned
+
+    def forward(self, x, rois):
+        require_cuda(x, "RoIAlign")
+        return hip_ops.roi_align_nhwc(hip_ops.nchw_to_nhwc(x), rois, self.output_size, self.spatial_scale,
+                                      self.sampling_ratio, self.aligned)
+
+
 class HarNetRoIHead(PlanOwner, nn.Module):
-    def __init__(self, n_class, roi_size, spatial_scale, classifier, in_channels=512):
+    def __init__(self, n_class, roi_size, spatial_scale, classifier, in_channels=512, roi_op="pool"):
+        """``roi_op`` (added, non-breaking): "pool" = the reference's RoIPool (nets/classify.py:17), "align" =
+        torchvision-style RoIAlign (sampling_ratio 2, aligned=False; change ``self.roi``'s attributes for others)."""
         super().__init__()
         self.classifier = classifier
         self.cls_loc = nn.Linear(in_channels, n_class * 4)
         self.score = nn.Linear(in_channels, n_class)
-        self.roi = RoIPool((roi_size, roi_size), spatial_scale)
+        if roi_op == "pool":
+            self.roi = RoIPool((roi_size, roi_size), spatial_scale)
+        elif roi_op == "align":
+            self.roi = RoIAlign((roi_size, roi_size), spatial_scale, sampling_ratio=2, aligned=False)
+        else:
+            raise ValueError(f"roi_op must be 'pool' or 'align', got {roi_op!r}")
+        self.roi_op = roi_op
         self._init_plan_owner()
 
     def _pack(self, dev):
@@ -60,8 +82,12 @@ class HarNetRoIHead(PlanOwner, nn.Module):
             raise TsodError("only the reference's HarNetClassifier (mean over the 7x7 bins) has a HIP path")
         n = feat.shape[0]
         rois = rois.reshape(n, -1, 4)
-        fc7 = hip_ops.roi_pool_avg_nhwc(feat, rois, roi_indices, img_size[0], img_size[1], self.roi.output_size,
-                                        self.roi.spatial_scale)
+        if isinstance(self.roi, RoIAlign):
+            fc7 = hip_ops.roi_align_avg_nhwc(feat, rois, roi_indices, img_size[0], img_size[1], self.roi.output_size,
+                                             self.roi.spatial_scale, self.roi.sampling_ratio, self.roi.aligned)
+        else:
+            fc7 = hip_ops.roi_pool_avg_nhwc(feat, rois, roi_indices, img_size[0], img_size[1], self.roi.output_size,
+                                            self.roi.spatial_scale)
         w, b, n_loc, n_sc = self._pack(feat.device)
         both = hip_ops.linear(fc7, w, b)                       # [n*R, pad4(5*n_class)]
         # views into the fused output (row pitch 408 for 81 classes): same values and shapes as the reference's two

@@ -8,7 +8,7 @@ FasterRCNNTrainer (nets/frcnn_training.py:203-217, 251-260, 289-298):
   * the head receives img_size = x.shape[2:] = (H,W)     (nets/frcnn.py:33,39, quirk Q2)
   * roi_indices = arange(B), int32                        (frcnn_training.py:291, quirk Q6)
 
-Added, non-breaking: ``backbone`` = "hardnet39" (the reference's default extractor) | "hardnet68" |
+Added, non-breaking: ``roi_op`` = "pool" (the reference's RoIPool, default) | "align" (RoIAlign); ``backbone`` = "hardnet39" (the reference's default extractor) | "hardnet68" |
 "resnet50" (resnet50(include_top=False): stride 32, 2048 channels - the composition BASELINE names).
 """
 from __future__ import annotations
@@ -39,7 +39,7 @@ def _make_extractor(backbone):
 
 class FasterRCNN(nn.Module):
     def __init__(self, num_classes, mode="training", feat_stride=16, anchor_scales=[8, 16, 32], ratios=[0.5, 1, 2],
-                 backbone="hardnet39"):
+                 backbone="hardnet39", roi_op="pool"):
         super().__init__()
         self.backbone = backbone
         self.extractor, feat_ch, native_stride = _make_extractor(backbone)
@@ -49,7 +49,7 @@ class FasterRCNN(nn.Module):
         self.rpn = RegionProposalNetwork(feat_ch, ratios=ratios, anchor_scales=anchor_scales,
                                          feat_stride=self.feat_stride, mode=mode)
         self.head = HarNetRoIHead(n_class=num_classes + 1, roi_size=7, spatial_scale=1, classifier=self.classifier,
-                                  in_channels=feat_ch)
+                                  in_channels=feat_ch, roi_op=roi_op)
         self.__dict__["_uid"] = next(_UID)          # scratch ownership: (this detector, slot), see hip_ops._Arena
 
     def weights_version(self):
