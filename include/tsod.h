@@ -150,6 +150,13 @@ int tsod_dwconv3x3_f32(const float *in, int32_t N, int32_t H, int32_t W, int32_t
                        const float *w, const float *scale, const float *shift, int32_t stride, int32_t relu,
                        float *out, int32_t out_pitch, int32_t out_off, tsod_stream_t stream);
 
+/* Grouped 3x3 conv, pad 1, stride 1|2, C -> C channels in `groups` groups + per-channel scale/shift (folded BN) + activation:
+ * the conv2 of the ResNeXt bottleneck (models/resnet.py:46-47 with groups = 32, width_per_group = 4; factory :167-172).
+ * w is [C][3][3][C/groups]; C/groups must be a multiple of 4.  act / slope as in tsod_conv2d_desc. */
+int tsod_gconv3x3_f32(const float *in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_pitch, int32_t groups,
+                      const float *w, const float *scale, const float *shift, int32_t stride, int32_t act, float slope,
+                      float *out, int32_t out_pitch, tsod_stream_t stream);
+
 /* nn.Conv2d(2G, G, 1, groups=G) + bias: models/hardnet.py:196.
  * out[.., g] = w[g][0]*in[.., 2g] + w[g][1]*in[.., 2g+1] + bias[g].  w is [G][2]. */
 int tsod_gconv1x1_pair_f32(const float *in, int64_t pixels, int32_t G, int32_t in_pitch, const float *w,

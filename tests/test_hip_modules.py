@@ -78,6 +78,21 @@ def test_resnet34_basicblock_trunk(dev):
         _feat_close(m.to(dev)(x.to(dev)).cpu(), oracle.resnet_trunk(sd, x))
 
 
+def test_resnext50_32x4d_trunk(dev):
+    """models/resnet.py:167-172: the grouped bottleneck (32 groups x 4/8/16/32 channels) on the direct grouped-conv kernel;
+    the 1x1 convs around it stay on the implicit GEMM."""
+    from two_stage_object_detection_amd.models.resnet import resnext50_32x4d
+    torch.manual_seed(2)
+    m = resnext50_32x4d(include_top=False).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = _img((1, 3, 160, 224))
+    with torch.inference_mode():
+        ref = oracle.resnet_trunk(sd, x)
+        got = m.to(dev)(x.to(dev)).cpu()
+    assert got.shape == ref.shape == (1, 2048, 5, 7)
+    _feat_close(got, ref)
+
+
 def test_resnet_bn_fold_and_prelu_are_honoured(dev):
     """Non-trivial BN statistics and PReLU slopes (the seeded init has identity BN)."""
     from two_stage_object_detection_amd.models.resnet import ResNet, Bottleneck

@@ -60,6 +60,8 @@ _SIGNATURES = {
     "tsod_maxpool3x3s2_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "tsod_dwconv3x3_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                    c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
+    "tsod_gconv3x3_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                  c_int32, c_int32, c_float, c_void_p, c_int32, c_void_p]),
     "tsod_gconv1x1_pair_f32": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "tsod_nchw_to_nhwc_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "tsod_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

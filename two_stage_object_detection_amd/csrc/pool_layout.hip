@@ -208,6 +208,54 @@ nhwc_to_nchw_tile_kernel(const float *__restrict__ in, int C, long HW, int in_pi
     }
 }
 
+// Grouped 3x3 convolution, pad 1, stride 1|2, as many output as input channels (ResNeXt's conv2: models/resnet.py:46-47 with
+// groups = 32, width_per_group = 4 -> 4..32 channels per group) + folded BN + activation.  Tiny contractions (K = 9 * cpg per
+// output): plain FMA work, HBM-bound, no MFMA.  A thread owns one output-channel quad of one output pixel; the group's cpg
+// input channels of each tap are read as float4s (contiguous in NHWC), weights are [C][3][3][cpg].
+__global__ void __launch_bounds__(256)
+gconv3x3_kernel(const float *__restrict__ in, int N, int H, int W, int C, int in_pitch, int cpg, const float *__restrict__ w,
+                const float *__restrict__ scale, const float *__restrict__ shift, int stride, float neg_slope, float act_hi,
+                int OH, int OW, float *__restrict__ out, int out_pitch) {
+    const int quads = C >> 2;
+    const long total = (long)N * OH * OW * quads;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(t % quads);
+        long u = t / quads;
+        const int ow = (int)(u % OW);
+        u /= OW;
+        const int oh = (int)(u % OH);
+        const int n = (int)(u / OH);
+        const int co = 4 * q, gbase = co / cpg * cpg;               // first input channel of this quad's group
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * stride - 1 + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * stride - 1 + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const float *xp = in + (((long)n * H + ih) * W + iw) * in_pitch + gbase;
+                for (int c = 0; c < cpg; c += 4) {
+                    const float4 x4 = *reinterpret_cast<const float4 *>(xp + c);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const float4 w4 = *reinterpret_cast<const float4 *>(w + ((long)(co + o) * 9 + kh * 3 + kw) * cpg + c);
+                        acc[o] = fmaf(x4.x, w4.x, acc[o]); acc[o] = fmaf(x4.y, w4.y, acc[o]);
+                        acc[o] = fmaf(x4.z, w4.z, acc[o]); acc[o] = fmaf(x4.w, w4.w, acc[o]);
+                    }
+                }
+            }
+        }
+        float4 r;
+        float *rp = &r.x;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const float v = acc[o] * (scale ? scale[co + o] : 1.f) + (shift ? shift[co + o] : 0.f);
+            rp[o] = fminf(fmaxf(v, 0.f) + neg_slope * fminf(v, 0.f), act_hi);
+        }
+        *reinterpret_cast<float4 *>(out + (((long)n * OH + oh) * OW + ow) * out_pitch + co) = r;
+    }
+}
+
 inline int grid_for(long total, int threads, int cap) {
     const long b = (total + threads - 1) / threads;
     return (int)(b < cap ? b : cap);
@@ -266,6 +314,26 @@ extern "C" int tsod_dwconv3x3_f32(const float *in, int32_t N, int32_t H, int32_t
         else TSOD_DW(2, 2, 1);
     }
 #undef TSOD_DW
+    return tsod_launch_status();
+}
+
+extern "C" int tsod_gconv3x3_f32(const float *in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_pitch,
+                                 int32_t groups, const float *w, const float *scale, const float *shift, int32_t stride,
+                                 int32_t act, float slope, float *out, int32_t out_pitch, tsod_stream_t stream) {
+    TSOD_REQUIRE(in && w && out, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && groups > 0 && C % groups == 0 && (stride == 1 || stride == 2),
+                 TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(act >= TSOD_ACT_NONE && act <= TSOD_ACT_RELU, TSOD_ERR_INVALID_ARG);
+    const int cpg = C / groups;
+    TSOD_REQUIRE((cpg & 3) == 0, TSOD_ERR_UNSUPPORTED);            // whole float4s per group (ResNeXt: 4, 8, 16, 32)
+    TSOD_REQUIRE((in_pitch & 3) == 0 && (out_pitch & 3) == 0 && in_pitch >= C && out_pitch >= C, TSOD_ERR_ALIGNMENT);
+    TSOD_REQUIRE(tsod_aligned16(in) && tsod_aligned16(out) && tsod_aligned16(w), TSOD_ERR_ALIGNMENT);
+    const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+    const long total = (long)N * OH * OW * (C / 4);
+    const float neg_slope = act == TSOD_ACT_NONE ? 1.f : (act == TSOD_ACT_PRELU ? slope : 0.f);
+    const float act_hi = act == TSOD_ACT_RELU6 ? 6.f : __builtin_huge_valf();
+    hipLaunchKernelGGL(gconv3x3_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, tsod_stream(stream), in, N, H, W, C,
+                       in_pitch, cpg, w, scale, shift, stride, neg_slope, act_hi, OH, OW, out, out_pitch);
     return tsod_launch_status();
 }
 

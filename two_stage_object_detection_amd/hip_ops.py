@@ -30,7 +30,6 @@ class _Arena:
     def __init__(self, zero: bool = False):
         self._buf = {}
         self._retired = {}
-        self._tls = threading.local()
         self._zero = zero            # conv workspaces start with arrival tickets that must be zero when first used
 
     def _key(self, device):
@@ -216,6 +215,18 @@ def dwconv3x3_nhwc(x: torch.Tensor, w33c: torch.Tensor, scale=None, shift=None, 
         out = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
     check(lib().tsod_dwconv3x3_f32(ptr(x), N, H, W, C, P, in_off, ptr(w33c), ptr(scale), ptr(shift), stride,
                                    1 if relu else 0, ptr(out), out.shape[3], out_off, stream_ptr()), "dwconv3x3")
+    return out
+
+
+def gconv3x3_nhwc(x: torch.Tensor, w_packed: torch.Tensor, groups: int, scale=None, shift=None, stride=1, act=ACT_NONE,
+                  slope=0.0) -> torch.Tensor:
+    """Grouped 3x3 pad-1 conv on NHWC [N,H,W,C] -> [N,OH,OW,C]; w_packed is [C,3,3,C/groups] (ResNeXt's conv2)."""
+    require_cuda(x, "gconv3x3")
+    N, H, W, C = x.shape
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
+    check(lib().tsod_gconv3x3_f32(ptr(x), N, H, W, C, C, int(groups), ptr(w_packed.contiguous()), ptr(scale), ptr(shift),
+                                  int(stride), int(act), float(slope), ptr(out), C, stream_ptr()), "gconv3x3")
     return out
 
 

@@ -44,8 +44,9 @@ class _ResidualBlock(nn.Module):
         last = len(self._stage_names) - 1
         for i, (cname, bname) in enumerate(self._stage_names):
             conv, bn = getattr(self, cname), getattr(self, bname)
-            if conv.groups != 1:
-                raise TsodError("grouped 3x3 convolutions (ResNeXt) have no HIP kernel in this build")
+            if conv.groups != 1:                      # ResNeXt's grouped 3x3 (models/resnet.py:46-47): direct kernel, no MFMA
+                cur = self._emit_grouped(plan, conv, bn, cur, x, slope, f"{name}.{cname}")
+                continue
             pc = plan.packed(f"{name}.{cname}", lambda conv=conv, bn=bn: PackedConv(
                 conv.weight, dev, bn=bn, stride=conv.stride[0], pad=conv.padding[0], act=ACT_PRELU, slope=slope))
             oh, ow = pc.out_hw(cur.shape[1], cur.shape[2])
@@ -57,6 +58,27 @@ class _ResidualBlock(nn.Module):
         if identity is not x:
             plan.pool.release(identity)
         return cur
+
+
+    def _emit_grouped(self, plan: Plan, conv, bn, cur, x, slope, name):
+        from ..engine import fold_bn
+        C, groups, stride = conv.out_channels, conv.groups, conv.stride[0]
+        if conv.kernel_size != (3, 3) or conv.in_channels != C or (C // groups) % 4:
+            raise TsodError(f"{name}: only 3x3 grouped convs with as many output as input channels and a multiple of 4 "
+                            "channels per group have a HIP kernel (what resnext50_32x4d uses)")
+
+        def make():
+            w = conv.weight.detach().float().permute(0, 2, 3, 1).contiguous().to(plan.device)     # [C][3][3][C/groups]
+            sc, sh = fold_bn(bn)
+            return w, sc.to(plan.device), sh.to(plan.device)
+        w, sc, sh = plan.packed(name, make)
+        N, H, W, _ = cur.shape
+        out = plan.pool.alloc((N, (H - 1) // stride + 1, (W - 1) // stride + 1, C))
+        plan.call(lib().tsod_gconv3x3_f32, ptr(cur), N, H, W, C, cur.shape[3], groups, ptr(w), ptr(sc), ptr(sh), stride,
+                  ACT_PRELU, float(slope), ptr(out), C, keep=(cur, out, w, sc, sh))
+        if cur is not x:
+            plan.pool.release(cur)
+        return out
 
 
 class BasicBlock(_ResidualBlock):
