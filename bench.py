@@ -87,6 +87,8 @@ def parse(argv=None):
                     "tuning launches)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replays, serial schedule only "
                     "(for rocprofv3 --pmc passes: every dispatch then carries its own counter sample)")
+    ap.add_argument("--no-fuse-shortcut", action="store_true", help="ResNet: one launch per conv (the projection shortcuts as their "
+                    "own GEMMs + residual reads) instead of stacking them into their block's last 1x1 conv (A/B switch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs behind roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -124,11 +126,11 @@ def conv_event_times(plan, reps=5):
     out = []
     s = stream_ptr()
     for st in plan.conv_steps:
-        L.tsod_conv2d_f32(*st.args, s)
+        st.fn(*st.args, s)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            L.tsod_conv2d_f32(*st.args, s)
+            st.fn(*st.args, s)
         e1.record()
         e1.synchronize()
         out.append(e0.elapsed_time(e1) / reps)
@@ -160,6 +162,8 @@ def conv_algorithmic_bytes(plan):
         d = st.desc
         cin = sum(d.seg_len[i] for i in range(d.n_seg))
         tot += 4 * (d.N * d.H * d.W * cin + d.N * d.OH * d.OW * d.Cout + d.Cout * d.KH * d.KW * cin)
+        if d.c2 > 0:                                  # second source of a fused shortcut: the pixels it taps + its weights
+            tot += 4 * (d.N * d.OH * d.OW * d.c2 + d.Cout * d.c2)
         if d.res_pitch > 0:
             tot += 4 * d.N * d.OH * d.OW * d.Cout
     return tot
@@ -181,7 +185,7 @@ def pmc_child(args, dev):
         L, s = lib(), stream_ptr()
         for _ in range(2):                                  # pass 1 warms caches / code objects, pass 2 is the sample
             for st in plan.conv_steps:
-                L.tsod_conv2d_f32(*st.args, s)
+                st.fn(*st.args, s)
         torch.cuda.synchronize()
 
 
@@ -353,6 +357,8 @@ def main(argv=None):
     model = model.to(dev).eval()
     if args.precision == "bf16x3":
         model.extractor.set_conv_precision("bf16x3")
+    if args.no_fuse_shortcut:
+        model.extractor.fuse_shortcut = False
 
     def images(r):
         return torch.rand(B, 3, args.height, args.width, generator=torch.Generator().manual_seed(1234 + r))

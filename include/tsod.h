@@ -103,6 +103,13 @@ typedef struct tsod_conv2d_desc {
                               chip-waves of whole tiles, left-over tiles K-sliced to fill the last wave);
                               0 = built-in cost model chooses */
     int32_t precision;     /* TSOD_PREC_* (0 = F32) */
+    /* optional SECOND source (tsod_conv2d_dual_f32; c2 = 0: none).  k in [KH*KW*Cin, KH*KW*Cin + c2) contracts channel
+     * in2_off + (k - KH*KW*Cin) of pixel (oh*stride2, ow*stride2) of in2 [N][H2][W2][in2_pitch]: a strided 1x1 tap, i.e. a
+     * bottleneck's last 1x1 conv and its projection shortcut (models/resnet.py:70-74 with :114-116) as ONE GEMM
+     *   out = act( [y | x_strided] . [W3*s3 | Wd*sd]^T + (b3 + bd) )
+     * (the caller folds both BN scales into the stacked weights [Cout][KH*KW*Cin + c2] and adds the shifts).
+     * Requires one channel segment, Cin % 32 == 0 and KH*KW*Cin % 32 == 0 (K-steps never straddle the sources). */
+    int32_t c2, in2_pitch, in2_off, stride2, H2, W2;
 } tsod_conv2d_desc;
 
 /* Packed weight layout Wp: [Cout][KH][KW][Cin] f32 (k = (kh*KW + kw)*Cin + ci, ci running over
@@ -130,6 +137,11 @@ int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const float *w_p
                     const float *scale /* [Cout] or NULL (=1) */, const float *shift /* [Cout] or NULL (=0) */,
                     const float *residual /* or NULL */, float *out,
                     void *workspace, size_t workspace_bytes, tsod_stream_t stream);
+
+/* The same with a second source tensor (desc.c2 > 0, see tsod_conv2d_desc); in2 == NULL iff desc.c2 == 0. */
+int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, const float *in2, const float *w_packed,
+                         const float *scale, const float *shift, const float *residual, float *out,
+                         void *workspace, size_t workspace_bytes, tsod_stream_t stream);
 
 /* nn.Linear (nets/classify.py:13,15): out[M,N] = in[M,K] @ w[N,K]^T + bias.  K % 4 == 0. */
 int tsod_linear_f32(const float *in, int32_t M, int32_t K, int32_t in_pitch, const float *w /* [N][K] */,

@@ -39,6 +39,7 @@ class ConvDesc(Structure):
         ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad_h", c_int32), ("pad_w", c_int32),
         ("OH", c_int32), ("OW", c_int32), ("act", c_int32), ("slope", c_float),
         ("res_pitch", c_int32), ("res_off", c_int32), ("tile", c_int32), ("split_k", c_int32), ("precision", c_int32),
+        ("c2", c_int32), ("in2_pitch", c_int32), ("in2_off", c_int32), ("stride2", c_int32), ("H2", c_int32), ("W2", c_int32),
     ]
 
 
@@ -54,6 +55,8 @@ _SIGNATURES = {
     "tsod_conv2d_resolve": (c_int, [POINTER(ConvDesc), POINTER(c_int32), POINTER(c_int32)]),
     "tsod_conv2d_f32": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
+    "tsod_conv2d_dual_f32": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
     "tsod_linear_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32,
                                 c_void_p, c_size_t, c_void_p]),
     "tsod_linear_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
@@ -174,7 +177,8 @@ def require_cuda(t, what: str) -> None:
 
 def make_conv_desc(*, N, H, W, in_pitch, segs, Cout, out_pitch, out_off=0, KH=1, KW=1, stride=1, pad_h=0, pad_w=0,
                    OH=None, OW=None, act=ACT_NONE, slope=0.0, res_pitch=0, res_off=0, tile=TILE_AUTO, split_k=0,
-                   precision=0) -> ConvDesc:
+                   precision=0, src2=None) -> ConvDesc:
+    """``src2`` = (channels, pitch, channel offset, stride, H2, W2) of the optional second source (tsod_conv2d_dual_f32)."""
     d = ConvDesc()
     d.N, d.H, d.W, d.in_pitch = N, H, W, in_pitch
     d.n_seg = len(segs)
@@ -187,4 +191,6 @@ def make_conv_desc(*, N, H, W, in_pitch, segs, Cout, out_pitch, out_off=0, KH=1,
     d.act, d.slope = act, float(slope)
     d.res_pitch, d.res_off, d.tile, d.split_k = res_pitch, res_off, tile, split_k
     d.precision = int(precision)
+    if src2 is not None:
+        d.c2, d.in2_pitch, d.in2_off, d.stride2, d.H2, d.W2 = (int(v) for v in src2)
     return d

@@ -63,6 +63,13 @@ struct ConvParams {
     unsigned out_bytes, res_bytes;
     unsigned in_bytes, w_bytes;   // buffer-descriptor extents (hardware bounds check: out of range reads 0)
     int vec_epilogue;             // 1: channels/pitches/offsets are multiples of 4 -> dwordx4 epilogue
+    // optional SECOND source (a strided 1x1 tap of another tensor, e.g. the block input under a projection shortcut):
+    // k in [K1, K1 + c2) reads channel in2_off + (k - K1) of pixel (oh * stride2, ow * stride2) of in2 [N][H2][W2][in2_pitch]
+    const float *in2;
+    unsigned in2_bytes;
+    int K1, c2, in2_pitch, in2_off, stride2, H2, W2;
+    int uniform_tap;              // 1: Cin % K-step == 0 and one channel segment: a K-step lies inside ONE filter tap and one
+                                  //    contiguous channel run, so (kh, kw, channel base) are wave-uniform and live on the scalar unit
     float neg_slope, act_hi;      // activation as min(max(v,0) + neg_slope*min(v,0), act_hi)
     float inv_cin, inv_kw;        // reciprocals for the branch-free k -> (kh, kw, ci) split
 };
@@ -192,9 +199,11 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     // ---- per-thread staging geometry (all offsets are 32-bit BYTE offsets into buffer descriptors)
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, (short)0, (int)p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, (short)0, (int)p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.in2 ? p.in2 : p.in), (short)0,
+                                                                             (int)(p.in2 ? p.in2_bytes : 0u), 0x00020000);
     const int c4 = (tid % TPR) * 4;  // k offset of this thread's chunk inside the K-step
     const int r0 = tid / TPR;        // 0..RPP-1
-    unsigned a_base[A_ROWS];
+    unsigned a_base[A_ROWS], a2_base[A_ROWS];
     int a_ih0[A_ROWS], a_iw0[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
@@ -208,10 +217,12 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
             a_iw0[i] = ow * p.stride - p.pad_w;
             // may wrap below zero for border rows; adding a valid tap's delta brings it back in range
             a_base[i] = (unsigned)((((long)img * p.H + a_ih0[i]) * p.W + a_iw0[i]) * p.in_pitch) * 4u;
+            a2_base[i] = p.c2 > 0 ? (unsigned)((((long)img * p.H2 + oh * p.stride2) * p.W2 + ow * p.stride2) * p.in2_pitch + p.in2_off) * 4u : kOOB;
         } else {
             a_ih0[i] = INT_MIN / 2;
             a_iw0[i] = INT_MIN / 2;
             a_base[i] = 0;
+            a2_base[i] = kOOB;
         }
     }
     constexpr int B_BASES = PREC ? B_TASKS : B_ROWS;
@@ -235,7 +246,48 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     // written to LDS at the end of step kt+1, so a workgroup tolerates ~2 K-steps of memory latency (a lone
     // workgroup per CU is otherwise bound by one L2/HBM round trip per K-step).
     float4 ra0[A_ROWS], rb0[B_ROWS], ra1[A_ROWS], rb1[B_ROWS];
+    // uniform-tap fast path: (kh, kw, channel base) of the K-step being loaded, advanced with scalar adds / compares
+    int u_kh = 0, u_kw = 0, u_ci = 0;
+    if (p.uniform_tap) {
+        const int kb = kt_begin * kBK;
+        const int seg0 = kb / p.Cin;                  // once per workgroup
+        u_ci = kb - seg0 * p.Cin;
+        u_kh = seg0 / p.KW;
+        u_kw = seg0 - u_kh * p.KW;
+    }
     auto load_global = [&](float4(&ra)[A_ROWS], float4(&rb)[B_ROWS]) {
+        if (p.uniform_tap) {
+            // the per-thread part of the address is the constant c4; everything else about this K-step is wave-uniform
+            if (kq * kBK >= p.K1) {                   // K-steps past the first source's K: the second source (a 1x1 tap, always in range)
+                const unsigned d2 = (unsigned)((kq * kBK - p.K1 + c4) * 4);
+#pragma unroll
+                for (int i = 0; i < A_ROWS; ++i) ra[i] = buffer_load4(rs_in2, a2_base[i] != kOOB ? a2_base[i] + d2 : kOOB);
+            } else {
+                const unsigned delta = (unsigned)(((u_kh * p.W + u_kw) * p.in_pitch + p.seg_off[0] + u_ci + c4) * 4);
+#pragma unroll
+                for (int i = 0; i < A_ROWS; ++i) {
+                    const int ih = a_ih0[i] + u_kh, iw = a_iw0[i] + u_kw;
+                    const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                    ra[i] = buffer_load4(rs_in, ok ? a_base[i] + delta : kOOB);
+                }
+            }
+            if constexpr (PREC == 0) {
+#pragma unroll
+                for (int i = 0; i < B_ROWS; ++i) rb[i] = buffer_load4(rs_w, b_base[i] != kOOB ? b_base[i] + (unsigned)k * 4u : kOOB);
+            } else {
+                const unsigned goff = (unsigned)kq * (unsigned)(GPR * 48);
+#pragma unroll
+                for (int i = 0; i < B_TASKS; ++i) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) rb[3 * i + q] = buffer_load4(rs_w, b_base[i] != kOOB ? b_base[i] + goff + 16u * q : kOOB);
+                }
+            }
+            u_ci += kBK;
+            if (u_ci >= p.Cin) { u_ci = 0; if (++u_kw == p.KW) { u_kw = 0; ++u_kh; } }
+            k += kBK;
+            ++kq;
+            return;
+        }
         // k -> (filter tap, channel) without divisions or loops: exact for k < 2^21
         const int seg = (int)(((float)k + 0.5f) * p.inv_cin);
         const int ci = k - seg * p.Cin;
@@ -714,6 +766,14 @@ int validate(const tsod_conv2d_desc *d) {
     TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->tile == TSOD_TILE_AUTO || kTiles[d->tile].bf16x3, TSOD_ERR_UNSUPPORTED);
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
     TSOD_REQUIRE(M < (int64_t)INT_MAX, TSOD_ERR_UNSUPPORTED);
+    if (d->c2 != 0) {                                   // second source: a strided 1x1 tap of another tensor
+        TSOD_REQUIRE(d->c2 > 0 && (d->c2 & 3) == 0 && d->stride2 > 0 && d->H2 > 0 && d->W2 > 0, TSOD_ERR_INVALID_ARG);
+        TSOD_REQUIRE((d->in2_pitch & 3) == 0 && (d->in2_off & 3) == 0, TSOD_ERR_ALIGNMENT);
+        TSOD_REQUIRE(d->in2_off >= 0 && d->in2_off + d->c2 <= d->in2_pitch, TSOD_ERR_INVALID_ARG);
+        TSOD_REQUIRE((d->OH - 1) * d->stride2 < d->H2 && (d->OW - 1) * d->stride2 < d->W2, TSOD_ERR_INVALID_ARG);
+        // K-steps must not straddle the two sources, and the fast (wave-uniform tap) loader is the one that knows about them
+        TSOD_REQUIRE(d->n_seg == 1 && (d->KH * d->KW * d->seg_len[0]) % 32 == 0 && d->seg_len[0] % 32 == 0, TSOD_ERR_UNSUPPORTED);
+    }
     return TSOD_OK;
 }
 
@@ -721,6 +781,15 @@ int desc_cin(const tsod_conv2d_desc *d) {
     int c = 0;
     for (int s = 0; s < d->n_seg; ++s) c += d->seg_len[s];
     return c;
+}
+
+// contraction length: the filter taps over the first source + the second source's channels
+int desc_k(const tsod_conv2d_desc *d) { return d->KH * d->KW * desc_cin(d) + (d->c2 > 0 ? d->c2 : 0); }
+
+// a tile's K-step must divide both the channel count (uniform taps) and K1 when there is a second source
+bool tile_ok_for(const tsod_conv2d_desc *d, int bk) {
+    if (d->c2 <= 0) return true;
+    return desc_cin(d) % bk == 0 && (d->KH * d->KW * desc_cin(d)) % bk == 0;
 }
 
 int g_cu_count = 0;
@@ -752,7 +821,7 @@ struct Sched {
 Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
     Sched s;
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
-    const int K = d->KH * d->KW * desc_cin(d);
+    const int K = desc_k(d);
     const int bk = kTiles[tile].bk;
     const int ksteps = (K + bk - 1) / bk;
     s.tile = tile; s.bm = kTiles[tile].bm; s.bn = kTiles[tile].bn;
@@ -805,12 +874,13 @@ Sched resolve(const tsod_conv2d_desc *d) {
     for (int t = 1; t < TSOD_TILE_COUNT; ++t) {
         if (d->tile != TSOD_TILE_AUTO && d->tile != t) continue;
         if (d->precision && !kTiles[t].bf16x3) continue;
+        if (!tile_ok_for(d, kTiles[t].bk) && d->tile != t) continue;
         if (d->split_k != 0) {
             const Sched s = make_sched(d, t, d->split_k);
             if (s.cost < best.cost) best = s;
             continue;
         }
-        const int K = d->KH * d->KW * desc_cin(d);
+        const int K = desc_k(d);
         const int ksteps = (K + kTiles[t].bk - 1) / kTiles[t].bk;
         for (int mode : {1, -1, 2, 4, 8, 16}) {
             if (mode > 1 && ksteps / mode < 2) continue;
@@ -846,9 +916,17 @@ extern "C" size_t tsod_conv2d_workspace_bytes(const tsod_conv2d_desc *d) {
 extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const float *w_packed, const float *scale,
                                const float *shift, const float *residual, float *out, void *workspace,
                                size_t workspace_bytes, tsod_stream_t stream) {
+    if (d != nullptr && d->c2 != 0) return TSOD_ERR_INVALID_ARG;       // a second source needs tsod_conv2d_dual_f32
+    return tsod_conv2d_dual_f32(d, in, nullptr, w_packed, scale, shift, residual, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, const float *in2, const float *w_packed,
+                                    const float *scale, const float *shift, const float *residual, float *out,
+                                    void *workspace, size_t workspace_bytes, tsod_stream_t stream) {
     const int rc = validate(d);
     if (rc != TSOD_OK) return rc;
     TSOD_REQUIRE(in && w_packed && out, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE((d->c2 > 0) == (in2 != nullptr) && (!in2 || tsod_aligned16(in2)), TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(tsod_aligned16(in) && tsod_aligned16(w_packed), TSOD_ERR_ALIGNMENT);
     if (residual) TSOD_REQUIRE(d->res_off >= 0 && d->res_pitch >= d->res_off + d->Cout, TSOD_ERR_INVALID_ARG);
 
@@ -867,8 +945,14 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
     p.OH = d->OH; p.OW = d->OW; p.act = d->act; p.slope = d->slope;
     p.res_pitch = d->res_pitch; p.res_off = d->res_off;
     p.M = d->N * d->OH * d->OW;
-    p.K = d->KH * d->KW * p.Cin;
+    p.K1 = d->KH * d->KW * p.Cin;
+    p.K = desc_k(d);
+    p.in2 = in2; p.c2 = d->c2 > 0 ? d->c2 : 0; p.in2_pitch = d->in2_pitch; p.in2_off = d->in2_off;
+    p.stride2 = d->stride2; p.H2 = d->H2; p.W2 = d->W2;
     {
+        const uint64_t in2_bytes = in2 ? (uint64_t)d->N * d->H2 * d->W2 * d->in2_pitch * sizeof(float) : 0;
+        TSOD_REQUIRE(in2_bytes < 0xFFFFFFF0ull, TSOD_ERR_UNSUPPORTED);
+        p.in2_bytes = (unsigned)in2_bytes;
         const uint64_t in_bytes = (uint64_t)d->N * d->H * d->W * d->in_pitch * sizeof(float);
         // bf16x3 weights are pre-split: [Cout][ceil(K/8)][hi|mid|lo][8] bf16 = 48 bytes per 8 k (tsod_pack_conv_weight_bf16x3)
         const uint64_t w_bytes = d->precision == TSOD_PREC_BF16X3 ? (uint64_t)d->Cout * ((p.K + 7) / 8) * 48
@@ -892,6 +976,8 @@ extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const
         p.inv_kw = 1.0f / (float)d->KW;
     }
     const Sched sc = resolve(d);
+    p.uniform_tap = (d->n_seg == 1 && p.Cin % kTiles[sc.tile].bk == 0) ? 1 : 0;
+    TSOD_REQUIRE(p.c2 == 0 || (p.uniform_tap && p.K1 % kTiles[sc.tile].bk == 0), TSOD_ERR_UNSUPPORTED);
     p.ksteps = (p.K + kTiles[sc.tile].bk - 1) / kTiles[sc.tile].bk;
     p.tiles_m = sc.tiles_m; p.tiles_n = sc.tiles_n;
     p.dp_tiles = sc.dp_tiles; p.split = sc.split; p.ksteps_per_split = sc.ksteps_per_split;

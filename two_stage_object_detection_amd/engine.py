@@ -56,6 +56,29 @@ class PackedConv:
         return ((H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw_logical) // self.stride + 1)
 
 
+class FusedShortcutConv:
+    """The last 1x1 conv of a residual block and its projection shortcut as ONE stacked-K GEMM (tsod_conv2d_dual_f32):
+        out = act( [y | x(strided)] . [W3 * s3 | Wd * sd]^T + (b3 + bd) )
+    (reference: out = bn3(conv3(y)); identity = bn_d(conv_d(x)); out += identity; relu - models/resnet.py:70-76 with the
+    downsample of :114-116).  Both BN scales are folded into the stacked weights in f64 and rounded once to f32 (the separate
+    form rounds the two scaled sums and their add instead: differences ~1e-7 relative, inside the feature bar)."""
+
+    def __init__(self, conv3_w, bn3, ds_w, ds_bn, ds_stride, device, act, slope):
+        s3, b3 = fold_bn(bn3)
+        sd, bd = fold_bn(ds_bn)
+        w3 = conv3_w.detach().double().cpu().flatten(1) * s3.double().view(-1, 1)          # [Cout, C1]
+        wd = ds_w.detach().double().cpu().flatten(1) * sd.double().view(-1, 1)             # [Cout, C2]
+        self.w = torch.cat([w3, wd], dim=1).float().contiguous().to(device)                # [Cout, C1 + C2]
+        self.cout, self.cin, self.c2 = self.w.shape[0], w3.shape[1], wd.shape[1]
+        self.cin_src, self.kh, self.kw, self.kw_logical = self.cin + self.c2, 1, 1, 1      # (FLOP accounting: both GEMMs)
+        self.stride, self.pad, self.act, self.slope, self.stride2 = 1, 0, act, float(slope), int(ds_stride)
+        self.scale = None
+        self.shift = (b3.double() + bd.double()).float().to(device)
+
+    def out_hw(self, H, W):
+        return H, W
+
+
 def weights_bf16x3(pc) -> torch.Tensor:
     """The pre-split bf16x3 image of a packed layer's weights (PackedConv or a compatible holder), made on first use and
     kept beside the f32 weights."""
@@ -109,13 +132,13 @@ def _merge_adjacent(segs):
 
 # --------------------------------------------------------------------------- plan
 class ConvStep:
-    __slots__ = ("desc", "args", "name", "flops", "ws_bytes", "pc")
+    __slots__ = ("desc", "args", "name", "flops", "ws_bytes", "pc", "fn", "w_index", "ws_index")
 
     def choose(self, tile: int, split_k: int, precision: int):
         """Pin (tile, K-slice schedule, arithmetic); the weight argument follows the arithmetic (f32 or pre-split bf16x3)."""
         d = self.desc
         d.tile, d.split_k, d.precision = int(tile), int(split_k), int(precision)
-        self.args[2] = ptr(weights_bf16x3(self.pc)) if precision == _ffi.PREC_BF16X3 else ptr(self.pc.w)
+        self.args[self.w_index] = ptr(weights_bf16x3(self.pc)) if precision == _ffi.PREC_BF16X3 else ptr(self.pc.w)
 
 
 class Plan:
@@ -153,31 +176,38 @@ class Plan:
     MAX_TENSOR_BYTES = 0xF0000000
 
     def conv(self, pc: PackedConv, x: torch.Tensor, out: torch.Tensor, *, segs=None, out_off=0, residual=None,
-             name="conv", tile=0, split_k=0, precision=None):
-        """x [N,H,W,P] -> out [N,OH,OW,Pout] (channel slice [out_off, out_off+Cout))."""
+             name="conv", tile=0, split_k=0, precision=None, x2=None, stride2=1):
+        """x [N,H,W,P] -> out [N,OH,OW,Pout] (channel slice [out_off, out_off+Cout)).  ``x2`` [N,H2,W2,P2]: second source of
+        a stacked-weight 1x1 conv (``pc`` = FusedShortcutConv): its last ``pc.c2`` K columns read pixel (oh*stride2, ow*stride2)."""
         N, H, W, P = x.shape
         OH, OW = pc.out_hw(H, W)
         assert tuple(out.shape[:3]) == (N, OH, OW), (out.shape, (N, OH, OW))
         precision = self.precision if precision is None else precision
-        per_img = max(H * W * P, OH * OW * out.shape[3], 0 if residual is None else OH * OW * residual.shape[3]) * 4
+        per_img = max(H * W * P, OH * OW * out.shape[3], 0 if residual is None else OH * OW * residual.shape[3],
+                      0 if x2 is None else x2.shape[1] * x2.shape[2] * x2.shape[3]) * 4
         if N > 1 and per_img * N >= self.MAX_TENSOR_BYTES:
             group = max(1, self.MAX_TENSOR_BYTES // per_img)
             for n0 in range(0, N, group):
                 n1 = min(N, n0 + group)
                 self.conv(pc, x[n0:n1], out[n0:n1], segs=segs, out_off=out_off,
                           residual=None if residual is None else residual[n0:n1], name=f"{name}[{n0}:{n1}]", tile=tile,
-                          split_k=split_k, precision=precision)
+                          split_k=split_k, precision=precision, x2=None if x2 is None else x2[n0:n1], stride2=stride2)
             return out
         segs = [(0, pc.cin)] if segs is None else _merge_adjacent(segs)
         d = make_conv_desc(N=N, H=H, W=W, in_pitch=P, segs=segs, Cout=pc.cout, out_pitch=out.shape[3], out_off=out_off,
                            KH=pc.kh, KW=pc.kw, stride=pc.stride, pad_h=pc.pad, pad_w=pc.pad, OH=OH, OW=OW, act=pc.act,
                            slope=pc.slope, res_pitch=0 if residual is None else residual.shape[3], res_off=0,
-                           tile=tile, split_k=split_k, precision=precision)
+                           tile=tile, split_k=split_k, precision=precision,
+                           src2=None if x2 is None else (pc.c2, x2.shape[3], 0, stride2, x2.shape[1], x2.shape[2]))
         args = [byref(d), ptr(x), ptr(weights_bf16x3(pc)) if precision == _ffi.PREC_BF16X3 else ptr(pc.w), ptr(pc.scale),
                 ptr(pc.shift), ptr(residual), ptr(out), 0, 0]
-        self.steps.append([lib().tsod_conv2d_f32, args])
+        if x2 is not None:
+            args.insert(2, ptr(x2))                               # tsod_conv2d_dual_f32(desc, in, in2, w, ...)
+        self.steps.append([lib().tsod_conv2d_dual_f32 if x2 is not None else lib().tsod_conv2d_f32, args])
         st = ConvStep()
         st.desc, st.args, st.name, st.pc = d, args, name, pc
+        st.fn = self.steps[-1][0]
+        st.w_index, st.ws_index = (3, 8) if x2 is not None else (2, 7)
         st.flops = 2 * N * OH * OW * getattr(pc, "cout_real", pc.cout) * pc.kh * pc.kw_logical * pc.cin_src   # algorithmic
         st.ws_bytes = 0
         self.conv_steps.append(st)
@@ -198,8 +228,8 @@ class Plan:
                 self._retired.append(self.workspace)
             self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
         for st in self.conv_steps:
-            st.args[7] = ptr(self.workspace)
-            st.args[8] = self.workspace.numel()
+            st.args[st.ws_index] = ptr(self.workspace)
+            st.args[st.ws_index + 1] = self.workspace.numel()
         self.graph = None
         return self
 
@@ -248,7 +278,7 @@ class Plan:
         results = []
         for st in self.conv_steps:
             d = st.desc
-            K = d.KH * d.KW * sum(d.seg_len[i] for i in range(d.n_seg))
+            K = d.KH * d.KW * sum(d.seg_len[i] for i in range(d.n_seg)) + max(0, int(d.c2))
             ksteps = (K + 31) // 32
             M = d.N * d.OH * d.OW
             cands = []
@@ -265,16 +295,17 @@ class Plan:
             for tile, split, prec in cands:
                 st.choose(tile, split, prec)
                 args = list(st.args)
-                args[7], args[8] = ptr(big), big.numel()
+                args[st.ws_index], args[st.ws_index + 1] = ptr(big), big.numel()
                 s = stream_ptr()
-                rc = lib().tsod_conv2d_f32(*args, s)          # warm
+                conv_fn = st.fn
+                rc = conv_fn(*args, s)          # warm
                 if rc != 0:
                     continue                                  # a candidate the library refuses is skipped, not fatal
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 if concurrent == 1:
                     e0.record()
                     for _ in range(reps):
-                        rc |= lib().tsod_conv2d_f32(*args, s)
+                        rc |= conv_fn(*args, s)
                     e1.record()
                 else:
                     cur = torch.cuda.current_stream(self.device)
@@ -284,11 +315,11 @@ class Plan:
                     for st2 in side:
                         st2.wait_stream(cur)
                     for _ in range(reps):
-                        rc |= lib().tsod_conv2d_f32(*args, s)
+                        rc |= conv_fn(*args, s)
                         for ci, st2 in enumerate(side):
                             a2 = list(args)
-                            a2[7] = ptr(bigs[ci + 1])
-                            rc |= lib().tsod_conv2d_f32(*a2, st2.cuda_stream)
+                            a2[st.ws_index] = ptr(bigs[ci + 1])
+                            rc |= conv_fn(*a2, st2.cuda_stream)
                     for st2 in side:
                         cur.wait_stream(st2)
                     e1.record()
@@ -352,6 +383,9 @@ class PlanOwner:
       is stale (it would run the old folded weights)."""
     max_plans = 8
     conv_precision = "f32"       # "f32" | "bf16x3": default arithmetic of the dense convs of plans built from now on
+    fuse_shortcut = True         # ResNet: a bottleneck's last 1x1 conv + its projection shortcut as one stacked-K GEMM
+                                 # (set False + invalidate_packed() for the one-launch-per-conv plan, e.g. to pin a tile
+                                 # table recorded from it)
 
     def set_conv_precision(self, precision: str):
         """Arithmetic of the dense conv GEMMs: "f32" (v_mfma_f32_32x32x2_f32) or "bf16x3" (three exact bf16 pieces per

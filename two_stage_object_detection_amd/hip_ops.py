@@ -146,15 +146,24 @@ def _w3_for(w_packed: torch.Tensor) -> torch.Tensor:
 
 def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_logical=None, scale=None, shift=None,
                 residual=None, act=ACT_NONE, slope=0.0, segs=None, out=None, out_off=0, tile=0, split_k=0,
-                precision=0) -> torch.Tensor:
+                precision=0, x2=None, stride2=1, x2_off=0) -> torch.Tensor:
     """Implicit-GEMM convolution on an NHWC tensor [N,H,W,P].  ``w_packed`` is [Cout,KH,KW,Cin]
     (see pack_conv_weight); ``kw_logical`` is the filter width before zero-tap padding (it fixes OW).
     ``segs`` = [(channel offset, length), ...] inside the P-wide pixel (default: the first Cin
-    channels).  Returns / fills an NHWC output [N,OH,OW,Pout]."""
+    channels).  Returns / fills an NHWC output [N,OH,OW,Pout].
+    ``x2`` [N,H2,W2,P2] is the optional second source of tsod_conv2d_dual_f32: ``w_packed`` is then [Cout, K1 + C2] with the
+    last C2 columns contracting channels [x2_off, x2_off + C2) of pixel (oh*stride2, ow*stride2) of ``x2`` (``kernel`` =
+    (KH, KW, Cin) of the first source must be given through ``segs`` / a 1x1 filter: only 1x1 first sources here)."""
     require_cuda(x, "conv2d")
     assert x.is_contiguous() and w_packed.is_contiguous()
     N, H, W, P = x.shape
-    Cout, KH, KW, Cin = w_packed.shape
+    src2 = None
+    if x2 is not None:                         # stacked [Cout, Cin1 + C2] weights of a 1x1 conv + a strided 1x1 tap of x2
+        assert w_packed.dim() == 2 and x2.is_contiguous() and segs is not None and len(segs) == 1
+        Cout, KH, KW, Cin = w_packed.shape[0], 1, 1, segs[0][1]
+        src2 = (w_packed.shape[1] - Cin, x2.shape[3], x2_off, stride2, x2.shape[1], x2.shape[2])
+    else:
+        Cout, KH, KW, Cin = w_packed.shape
     segs = [(0, Cin)] if segs is None else segs
     assert sum(s[1] for s in segs) == Cin, "segments must add up to the packed Cin"
     OH = (H + 2 * pad - KH) // stride + 1
@@ -165,12 +174,12 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
     d = make_conv_desc(N=N, H=H, W=W, in_pitch=P, segs=segs, Cout=Cout, out_pitch=out.shape[3], out_off=out_off,
                        KH=KH, KW=KW, stride=stride, pad_h=pad, pad_w=pad, OH=OH, OW=OW, act=act, slope=slope,
                        res_pitch=0 if residual is None else residual.shape[-1], res_off=0, tile=tile, split_k=split_k,
-                       precision=precision)
+                       precision=precision, src2=src2)
     ws_bytes = lib().tsod_conv2d_workspace_bytes(byref(d))
     ws = CONV_ARENA.get(x.device, ws_bytes) if ws_bytes else None
     w_arg = _w3_for(w_packed) if precision == _ffi.PREC_BF16X3 else w_packed     # bf16x3 reads the pre-split weight image
-    check(lib().tsod_conv2d_f32(byref(d), ptr(x), ptr(w_arg), ptr(scale), ptr(shift), ptr(residual), ptr(out),
-                                ptr(ws), ws_bytes, stream_ptr()), "conv2d")
+    check(lib().tsod_conv2d_dual_f32(byref(d), ptr(x), ptr(x2), ptr(w_arg), ptr(scale), ptr(shift), ptr(residual), ptr(out),
+                                     ptr(ws), ws_bytes, stream_ptr()), "conv2d")
     return out
 
 

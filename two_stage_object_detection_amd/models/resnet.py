@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import hip_ops
 from .._ffi import ACT_NONE, ACT_PRELU, TsodError, lib, ptr, require_cuda
-from ..engine import PackedConv, Plan, PlanOwner, prelu_slope
+from ..engine import FusedShortcutConv, PackedConv, Plan, PlanOwner, prelu_slope
 
 
 def _conv(cin, cout, k, stride=1, pad=0, groups=1):
@@ -34,7 +34,14 @@ class _ResidualBlock(nn.Module):
         dev = plan.device
         slope = prelu_slope(self.relu)
         identity = x
-        if self.downsample is not None:
+        # projection shortcut + last 1x1 conv as ONE stacked-K GEMM (engine.FusedShortcutConv): one launch, no shortcut tensor
+        # written and re-read as residual.  Needs a 1x1 last conv (Bottleneck) and channel counts the K-steps divide.
+        last_name, last_bn = self._stage_names[-1]
+        last_conv = getattr(self, last_name)
+        fuse = (self.downsample is not None and getattr(plan, "fuse_shortcut", True) and last_conv.kernel_size == (1, 1)
+                and last_conv.groups == 1 and last_conv.in_channels % 32 == 0 and self.downsample[0].in_channels % 32 == 0
+                and self.downsample[0].kernel_size == (1, 1))
+        if self.downsample is not None and not fuse:
             ds_conv, ds_bn = self.downsample[0], self.downsample[1]
             pc = plan.packed(f"{name}.downsample", lambda: PackedConv(ds_conv.weight, dev, bn=ds_bn, stride=ds_conv.stride[0],
                                                                       act=ACT_NONE))
@@ -47,6 +54,16 @@ class _ResidualBlock(nn.Module):
             if conv.groups != 1:                      # ResNeXt's grouped 3x3 (models/resnet.py:46-47): direct kernel, no MFMA
                 cur = self._emit_grouped(plan, conv, bn, cur, x, slope, f"{name}.{cname}")
                 continue
+            if i == last and fuse:
+                ds_conv, ds_bn = self.downsample[0], self.downsample[1]
+                pc = plan.packed(f"{name}.{cname}+downsample", lambda conv=conv, bn=bn: FusedShortcutConv(
+                    conv.weight, bn, ds_conv.weight, ds_bn, ds_conv.stride[0], dev, ACT_PRELU, slope))
+                out = plan.pool.alloc((cur.shape[0], cur.shape[1], cur.shape[2], pc.cout))
+                plan.conv(pc, cur, out, segs=[(0, pc.cin)], name=f"{name}.{cname}+downsample", x2=x, stride2=pc.stride2)
+                if cur is not x:
+                    plan.pool.release(cur)
+                cur = out
+                continue
             pc = plan.packed(f"{name}.{cname}", lambda conv=conv, bn=bn: PackedConv(
                 conv.weight, dev, bn=bn, stride=conv.stride[0], pad=conv.padding[0], act=ACT_PRELU, slope=slope))
             oh, ow = pc.out_hw(cur.shape[1], cur.shape[2])
@@ -58,7 +75,6 @@ class _ResidualBlock(nn.Module):
         if identity is not x:
             plan.pool.release(identity)
         return cur
-
 
     def _emit_grouped(self, plan: Plan, conv, bn, cur, x, slope, name):
         from ..engine import fold_bn
@@ -152,6 +168,7 @@ class ResNet(PlanOwner, nn.Module):
         BN+PReLU, 3x3/s2 max pool, then the residual stages."""
         plan = Plan(device, self._packed_cache)
         plan.precision = 1 if self.conv_precision == "bf16x3" else 0
+        plan.fuse_shortcut = bool(self.fuse_shortcut)
         x4 = plan.pool.alloc((N, H, W, 4))
         plan.input_nhwc = x4
         stem = plan.packed("conv1", lambda: PackedConv(self.conv1.weight, device, bn=self.bn1, stride=2, pad=3, act=ACT_PRELU,
