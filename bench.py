@@ -79,6 +79,9 @@ def parse(argv=None):
     ap.add_argument("--precision", default="auto", choices=("f32", "bf16x3", "auto"), help="arithmetic of the conv GEMMs: f32 = "
                     "v_mfma_f32_32x32x2_f32; bf16x3 = three exact bf16 pieces per operand on v_mfma_f32_32x32x16_bf16 "
                     "(f32-accurate, gated by the same parity suite); auto = the autotuner picks per layer")
+    ap.add_argument("--autotune-concurrent", type=int, default=None, help="copies of a candidate in flight on separate streams while "
+                    "the in-flight tile table is tuned (default: --in-flight, i.e. 4: measured 697 -> 754 images/s on one box "
+                    "against tuning with 2 copies; 6 and 8 are no better)")
     ap.add_argument("--autotune-splits", default=None, help="comma list restricting the K-slice candidates of the autotuner")
     ap.add_argument("--in-flight", type=int, default=4, help="steps in flight: consecutive steps are issued round-robin on this "
                     "many HIP streams, each with its own graph and buffers (request-level pipelining of a batch-1 server)")
@@ -382,7 +385,7 @@ def main(argv=None):
             plan.autotune(verbose=args.verbose and rank == 0, splits=splits, concurrent=1, precisions=precs)
             tiles["serial"] = plan.export_tiles()
             if n_fly > 1:                                              # objective of an overlapped server: two copies in flight
-                plan.autotune(verbose=False, splits=splits, concurrent=2, precisions=precs)
+                plan.autotune(verbose=False, splits=splits, concurrent=max(2, args.autotune_concurrent or n_fly), precisions=precs)
                 tiles["in_flight"] = plan.export_tiles()
             else:
                 tiles["in_flight"] = tiles["serial"]

@@ -40,7 +40,7 @@ class InFlightDetector:
             if tiles is not None:
                 plan0.import_tiles(tiles)
             elif autotune:
-                plan0.autotune(concurrent=2 if depth > 1 else 1)
+                plan0.autotune(concurrent=depth if depth > 1 else 1, precisions=(0, 1))   # objective = this server's overlap
             self.tiles = plan0.export_tiles()
             for s in range(1, depth):                                    # the same tile choices in every slot's plan
                 model(example, slot=s)
