@@ -418,7 +418,7 @@ def main(argv=None):
             f32_leg = {"bound": "mfma", "achieved": round(fl32 / (sum(ms32) * 1e-3) / 1e12, 3), "peak": F32_MFMA_PEAK_TFLOPS,
                        "unit": "TFLOP/s", "frac": round(fl32 / (sum(ms32) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                        "kernel_ms_per_forward": round(sum(ms32), 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
-                       "note": "same 53 conv launches with every layer pinned to the f32-MFMA kernels (serial per-kernel "
+                       "note": "the same conv launches with every layer pinned to the f32-MFMA kernels (serial per-kernel "
                                "HIP-event times); not the timed path when --precision auto picks bf16x3"}
         # ---- schedule 1: strictly serial (one graph, one stream) + the per-kernel roofline that belongs to it
         plan.import_tiles(tiles["serial"])

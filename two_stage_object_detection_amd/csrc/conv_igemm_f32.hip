@@ -256,6 +256,11 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
         u_kw = seg0 - u_kh * p.KW;
     }
     auto load_global = [&](float4(&ra)[A_ROWS], float4(&rb)[B_ROWS]) {
+#ifdef TSOD_DIAG_NOLOAD
+        // timing diagnostic only (wrong results): after the first two K-steps no global load is issued, the staged registers
+        // are re-used - what the K loop costs when memory latency is taken out
+        if (kq > kt_begin + 1) { ++kq; k += kBK; return; }
+#endif
         if (p.uniform_tap) {
             // the per-thread part of the address is the constant c4; everything else about this K-step is wave-uniform
             if (kq * kBK >= p.K1) {                   // K-steps past the first source's K: the second source (a 1x1 tap, always in range)
@@ -401,19 +406,18 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
             if (do_load) load_global(lra, lrb);
 #pragma unroll
             for (int c = 0; c < CHUNKS; ++c) {
+                // six piece products per (A block, B block), smallest first; the product loop is OUTSIDE the block loops so that
+                // consecutive MFMAs write different accumulators wherever the wave owns more than one 32x32 block (a dependent
+                // back-to-back MFMA waits for the previous one's result: at 32 cycles per MFMA that wait is not negligible)
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0};          // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+                constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int q = 0; q < 6; ++q)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        f32x16 t = acc[i][j];
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], t, 0, 0, 0);   // lo  * hi
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], t, 0, 0, 0);   // hi  * lo
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], t, 0, 0, 0);   // mid * mid
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], t, 0, 0, 0);   // mid * hi
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], t, 0, 0, 0);   // hi  * mid
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], t, 0, 0, 0);   // hi  * hi
-                        acc[i][j] = t;
-                    }
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[q]], fb[j][PB[q]], acc[i][j], 0, 0, 0);
                 if (c + 1 < CHUNKS) load_frags(c + 1);
                 if (do_store) {                       // the next step's split + LDS writes ride behind this chunk's MFMAs
                     if (c == 0) {
