@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define TSOD_VERSION 100 /* 0.1.0 */
+#define TSOD_VERSION 200 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
+                            ticket area in the workspace), pitched tsod_detections_f32, new entry points */
 
 typedef void *tsod_stream_t; /* hipStream_t */
 

@@ -18,7 +18,7 @@ the modules raise on CPU tensors and on a missing extension.
 import importlib
 import sys
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
 
 def install_dropin(force: bool = False) -> None:

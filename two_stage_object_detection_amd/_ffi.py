@@ -123,6 +123,9 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, args
+        if l.tsod_version() != 200:
+            raise TsodError(f"{LIB_PATH} is version {l.tsod_version()}, this package binds version 200 of include/tsod.h: rebuild it "
+                            "(`make -C two_stage_object_detection_amd/csrc`)")
         _lib = l
     return _lib
 
