@@ -41,7 +41,8 @@ Every timed region (exactly K steps between barrier + synchronize on both sides,
   cpu_baseline     : the CPU oracle (torch CPU ops + C nms / roi_pool restatement of the reference's path) timed on this
                      box's host cores on the same workload (rank 0, N = 1 only).
   --check          : (N > 1) the gathered [N*B,300,6] records of the last step are compared on rank 0 with single-GPU
-                     forwards of every rank's images (boxes / scores <= 1e-3, classes bit-exact); a mismatch fails the run.
+                     forwards of every rank's images (records matched per image as sets: boxes / scores <= 1e-3, classes
+                     equal, <= 1 % unmatched - ranks tune their own tile tables, so bars, not bits); a mismatch fails the run.
 """
 import argparse
 import json
@@ -272,10 +273,33 @@ class Timer:
 
 
 def compare_records(got, ref, atol=1e-3):
-    """[n,300,6] records: class column bit-exact, box / score columns within atol, row for row."""
-    cls_equal = bool(torch.equal(got[..., 5], ref[..., 5]))
-    err = float((got[..., :5] - ref[..., :5]).abs().max())
-    return {"ok": cls_equal and err <= atol, "classes_equal": cls_equal, "max_abs_box_score": err, "images": int(got.shape[0])}
+    """[n,300,6] detection records (x1,y1,x2,y2,score,class) of the gathered result against single-GPU forwards.  Every rank
+    tunes its own tile / K-slice table, so two ranks sum in different orders: results agree to the parity bars, not bit for
+    bit, and a score pair closer than the f32 noise may swap two rows (or flip one NMS decision).  Records are therefore
+    matched per image as SETS (nearest box within atol, same position preferred): matched pairs must have equal classes and
+    scores within atol; at most 1 % of an image's records may be unmatched."""
+    n, R, _ = got.shape
+    unmatched, cls_bad, max_box, max_score, off = 0, 0, 0.0, 0.0, []
+    idx = torch.arange(R)
+    for i in range(n):
+        d = (got[i, :, None, :4] - ref[i, None, :, :4]).abs().amax(-1)              # [R,R]
+        best = torch.where(d[idx, idx] <= atol, idx, d.argmin(dim=1))
+        ok = d[idx, best] <= atol
+        u = int((~ok).sum())
+        unmatched += u
+        if u > max(3, R // 100):
+            off.append(i)
+        if ok.any():
+            gi, ri = idx[ok], best[ok]
+            max_box = max(max_box, float(d[gi, ri].max()))
+            max_score = max(max_score, float((got[i, gi, 4] - ref[i, ri, 4]).abs().max()))
+            bad = int((got[i, gi, 5] != ref[i, ri, 5]).sum())
+            cls_bad += bad
+            if bad and i not in off:
+                off.append(i)
+    return {"ok": not off and cls_bad == 0 and max_score <= atol, "images": int(n), "records_unmatched": unmatched,
+            "class_mismatch_on_matched": cls_bad, "max_abs_box_on_matched": max_box, "max_abs_score_on_matched": max_score,
+            "images_off": off}
 
 
 # ----------------------------------------------------------------------------------------------- rehearsal (no GPU)
