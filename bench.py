@@ -418,6 +418,8 @@ def main(argv=None):
                 tiles["in_flight"] = tiles["serial"]
             if args.tiles_file and rank == 0:
                 json.dump(tiles, open(args.tiles_file, "w"))
+        if not args.no_autotune:
+            model.autotune_heads(x)                                    # the two GEMMs outside the backbone plan
 
         gathered = [torch.empty((world * B, R_POST, 6), dtype=torch.float32, device=dev if nccl else "cpu")
                     for _ in range(n_fly)] if world > 1 else None

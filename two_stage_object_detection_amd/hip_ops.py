@@ -134,7 +134,8 @@ _W3_CACHE: dict = {}
 
 def _w3_for(w_packed: torch.Tensor) -> torch.Tensor:
     """Pre-split image of a weight tensor for the tensor-level wrapper (the engine keeps its own per layer)."""
-    key = (w_packed.data_ptr(), tuple(w_packed.shape), w_packed._version)
+    version = 0 if w_packed.is_inference() else w_packed._version       # inference tensors carry no version counter
+    key = (w_packed.data_ptr(), tuple(w_packed.shape), version)
     hit = _W3_CACHE.get(key)
     if hit is None or hit[0]() is not w_packed:
         import weakref
@@ -181,6 +182,34 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
     check(lib().tsod_conv2d_dual_f32(byref(d), ptr(x), ptr(x2), ptr(w_arg), ptr(scale), ptr(shift), ptr(residual), ptr(out),
                                      ptr(ws), ws_bytes, stream_ptr()), "conv2d")
     return out
+
+
+def tune_conv(x: torch.Tensor, w_packed: torch.Tensor, reps: int = 5, precisions=(0, 1), **kw) -> tuple[int, int, int]:
+    """Time every (tile, K-slice schedule, arithmetic) of ONE conv2d_nhwc call on its real operands with HIP events and return
+    the fastest as (tile, split_k, precision) - for the few GEMMs outside a backbone plan (the fused RPN conv, the fused head
+    GEMM).  A speed choice only: every candidate is f32-accurate."""
+    K = w_packed.numel() // w_packed.shape[0]
+    ksteps = (K + 31) // 32
+    best = None
+    for prec in precisions:
+        for tile in (_ffi.BF16X3_TILE_IDS if prec == _ffi.PREC_BF16X3 else _ffi.TILE_IDS):
+            for split in (1, -1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+                if split > 1 and ksteps // split < 2:
+                    continue
+                try:
+                    conv2d_nhwc(x, w_packed, tile=tile, split_k=split, precision=prec, **kw)          # warm (and validity)
+                except _ffi.TsodError:
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    conv2d_nhwc(x, w_packed, tile=tile, split_k=split, precision=prec, **kw)
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1) / reps
+                if best is None or t < best[0]:
+                    best = (t, tile, split, prec)
+    return best[1], best[2], best[3]
 
 
 def conv2d_resolve(d) -> tuple[int, int]:

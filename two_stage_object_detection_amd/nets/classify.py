@@ -89,10 +89,22 @@ class HarNetRoIHead(PlanOwner, nn.Module):
             fc7 = hip_ops.roi_pool_avg_nhwc(feat, rois, roi_indices, img_size[0], img_size[1], self.roi.output_size,
                                             self.roi.spatial_scale)
         w, b, n_loc, n_sc = self._pack(feat.device)
-        both = hip_ops.linear(fc7, w, b)                       # [n*R, pad4(5*n_class)]
+        # the fused Linear as a 1x1 "conv" over M = n*R rows: same GEMM kernel as tsod_linear_f32, with the tile / K-slice /
+        # arithmetic choice of autotune() when there is one
+        M, K = fc7.shape
+        tile, split, prec = self.__dict__.get("_gemm_choice", {}).get(M, (0, 0, 0))
+        both = hip_ops.conv2d_nhwc(fc7.view(1, 1, M, K), w.view(w.shape[0], 1, 1, K), shift=b, tile=tile, split_k=split,
+                                   precision=prec).view(M, w.shape[0])             # [n*R, pad4(5*n_class)]
         # views into the fused output (row pitch 408 for 81 classes): same values and shapes as the reference's two
         # Linear outputs; .contiguous() them if a consumer needs dense storage
         return both[:, :n_loc].view(n, -1, n_loc), both[:, n_loc:n_loc + n_sc].view(n, -1, n_sc)
+
+    def autotune(self, fc7: torch.Tensor):
+        """Pin the fastest (tile, K-slice schedule, arithmetic) of the fused cls_loc + score GEMM for M = fc7.shape[0] RoIs."""
+        w, b, _, _ = self._pack(fc7.device)
+        M, K = fc7.shape
+        self.__dict__.setdefault("_gemm_choice", {})[M] = hip_ops.tune_conv(fc7.view(1, 1, M, K), w.view(w.shape[0], 1, 1, K), shift=b)
+        return self._gemm_choice[M]
 
     def forward(self, x, rois, roi_indices, img_size):
         """x NCHW [n,C,Hf,Wf] (the reference's layout)."""

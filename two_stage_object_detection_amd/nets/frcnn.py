@@ -92,6 +92,17 @@ class FasterRCNN(nn.Module):
             return self.head.forward(base_feature, rois, roi_indices, img_size)
         raise ValueError(f"unknown mode {mode!r}")
 
+    def autotune_heads(self, x, slot=0):
+        """Time the candidates of the two GEMMs outside the backbone plan (fused RPN conv, fused head GEMM) for this input
+        geometry and pin the fastest (``extractor._plan_for(x).autotune()`` does the same for the backbone)."""
+        require_cuda(x, "FasterRCNN.autotune_heads")
+        with torch.inference_mode():
+            feat = self.extractor.forward_nhwc(x, slot)
+            rpn_choice = self.rpn.autotune(feat)
+            n_post = self.rpn.proposal_layer.counts()[1]
+            fc7 = torch.randn(x.shape[0] * n_post, self.head.cls_loc.in_features, device=x.device)
+            return rpn_choice, self.head.autotune(fc7)
+
     def detections(self, x, scale=1.):
         """[B,R,6] rows (x1,y1,x2,y2, max logit, arg-max class): SURVEY D5 / frcnn_training.py:311-319."""
         cls_locs, scores, rois, _ = self.forward(x, scale)

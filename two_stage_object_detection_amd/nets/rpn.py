@@ -117,11 +117,19 @@ class RegionProposalNetwork(PlanOwner, nn.Module):
         require_cuda(feat, "RegionProposalNetwork")
         n, h, w, _ = feat.shape
         pc, base, n_loc, n_sc = self._pack(feat.device)
-        fused = hip_ops.conv2d_nhwc(feat, pc.w, shift=pc.shift).view(n * h * w, pc.cout)
+        tile, split, prec = self.__dict__.get("_gemm_choice", {}).get((n, h, w), (0, 0, 0))
+        fused = hip_ops.conv2d_nhwc(feat, pc.w, shift=pc.shift, tile=tile, split_k=split, precision=prec).view(n * h * w, pc.cout)
         boxes, _, keys, anchor = hip_ops.rpn_decode(fused[:, :n_loc], fused[:, n_loc:n_loc + n_sc], base, n, h, w,
                                                     self.feat_stride, img_size[1], img_size[2],
                                                     self.proposal_layer.min_size * scale, want_anchors=want_anchors)
         return fused, self.proposal_layer.select(boxes, keys), anchor
+
+    def autotune(self, feat: torch.Tensor):
+        """Pin the fastest (tile, K-slice schedule, arithmetic) of the fused loc + score GEMM for this feature geometry."""
+        n, h, w, _ = feat.shape
+        pc = self._pack(feat.device)[0]
+        self.__dict__.setdefault("_gemm_choice", {})[(n, h, w)] = hip_ops.tune_conv(feat, pc.w, shift=pc.shift)
+        return self._gemm_choice[(n, h, w)]
 
     def forward_nhwc(self, feat: torch.Tensor, img_size, scale=1.):
         """feat NHWC [n,h,w,C] -> (rpn_locs [n,h*w*A,4], rpn_scores [n,h*w*A,2], rois [n,n_post,4], anchor [1,h*w*A,4])."""
