@@ -94,6 +94,8 @@ def test_detector_after_plan_autotune_and_through_the_serving_path(dev, r50):
         plan = model.extractor._plan_for(xg)
         before = plan.export_tiles()
         res = plan.autotune(reps=2, concurrent=2, precisions=(0, 1))     # bench.py --precision auto: f32 and bf16x3 compete
+        heads = model.autotune_heads(xg)                                 # ... and the fused RPN conv / head GEMM are tuned too
+        assert all(len(c) == 3 and c[2] in (0, 1) for c in heads)
         tuned = plan.export_tiles()
         assert len(res) == len(plan.conv_steps) == 49          # 53 convs, the four projection shortcuts ride in their conv3's GEMM
         assert all(t in range(1, 17) and p in (0, 1) for _, t, _, p in tuned)
@@ -113,6 +115,8 @@ def test_detector_after_plan_autotune_and_through_the_serving_path(dev, r50):
             assert (outs[4][..., :5] - det_ref[..., :5]).abs().max().item() <= 1e-3
         server.drain()
         plan.import_tiles(before)
+        model.rpn._gemm_choice.clear()
+        model.head._gemm_choice.clear()
 
 
 @pytest.mark.parametrize("backbone,shape", [("resnet50", (1, 3, 800, 1333)), ("resnet50", (2, 3, 320, 448)), ("hardnet39", (2, 3, 320, 448))])

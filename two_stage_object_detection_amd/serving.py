@@ -41,6 +41,7 @@ class InFlightDetector:
                 plan0.import_tiles(tiles)
             elif autotune:
                 plan0.autotune(concurrent=depth if depth > 1 else 1, precisions=(0, 1))   # objective = this server's overlap
+                model.autotune_heads(example)
             self.tiles = plan0.export_tiles()
             for s in range(1, depth):                                    # the same tile choices in every slot's plan
                 model(example, slot=s)
