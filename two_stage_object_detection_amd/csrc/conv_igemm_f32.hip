@@ -355,6 +355,9 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
         }
     };
     auto store_lds = [&](int buf, const float4(&ra)[A_ROWS], const float4(&rb)[B_ROWS]) {
+#ifdef TSOD_DIAG_NOSTORE
+        if (kq > kt_begin + 2) return;        // timing diagnostic only (wrong results): no split / LDS writes after the first steps
+#endif
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) store_chunk(buf, 0, r0 + RPP * i, ra[i]);
         store_b(buf, rb);
@@ -389,26 +392,30 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
             const unsigned char *As = reinterpret_cast<const unsigned char *>(smem + buf * STAGE) + (wm * WM + frag_row) * ROW_B;
             const unsigned char *Bs = reinterpret_cast<const unsigned char *>(smem + buf * STAGE + kPlanes * BM * kLDK) +
                                       (wn * WN + frag_row) * ROW_B;
-            bf16x8 fa[TM][3], fb[TN][3];
-            auto load_frags = [&](int c) {
+            // two fragment sets: chunk c + 1 is read into the other set BEFORE chunk c's MFMAs are issued, so its LDS latency
+            // lies under them (with one set the compiler re-reads into registers an MFMA has just consumed and the next MFMA
+            // waits for LDS three times per chunk)
+            bf16x8 fa[2][TM][3], fb[2][TN][3];
+            auto load_frags = [&](int c, int set) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
-                        fa[i][q] = *reinterpret_cast<const bf16x8 *>(As + q * BM * ROW_B + i * 32 * ROW_B + (((2 * c) ^ x0) << 4));
+                        fa[set][i][q] = *reinterpret_cast<const bf16x8 *>(As + q * BM * ROW_B + i * 32 * ROW_B + (((2 * c) ^ x0) << 4));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
-                        fb[j][q] = *reinterpret_cast<const bf16x8 *>(Bs + q * BN * ROW_B + j * 32 * ROW_B + (((2 * c) ^ x0) << 4));
+                        fb[set][j][q] = *reinterpret_cast<const bf16x8 *>(Bs + q * BN * ROW_B + j * 32 * ROW_B + (((2 * c) ^ x0) << 4));
             };
-            load_frags(0);
+            load_frags(0, 0);
             if (do_load) load_global(lra, lrb);
 #pragma unroll
             for (int c = 0; c < CHUNKS; ++c) {
+                const int cur = c & 1;
+                if (c + 1 < CHUNKS) load_frags(c + 1, cur ^ 1);
                 // six piece products per (A block, B block), smallest first; the product loop is OUTSIDE the block loops so that
-                // consecutive MFMAs write different accumulators wherever the wave owns more than one 32x32 block (a dependent
-                // back-to-back MFMA waits for the previous one's result: at 32 cycles per MFMA that wait is not negligible)
+                // consecutive MFMAs write different accumulators wherever the wave owns more than one 32x32 block
                 constexpr int PA[6] = {2, 0, 1, 1, 0, 0};          // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
                 constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -417,8 +424,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[q]], fb[j][PB[q]], acc[i][j], 0, 0, 0);
-                if (c + 1 < CHUNKS) load_frags(c + 1);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i][PA[q]], fb[cur][j][PB[q]], acc[i][j], 0, 0, 0);
                 if (do_store) {                       // the next step's split + LDS writes ride behind this chunk's MFMAs
                     if (c == 0) {
 #pragma unroll
