@@ -33,8 +33,9 @@
 extern "C" {
 #endif
 
-#define TSOD_VERSION 200 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
-                            ticket area in the workspace), pitched tsod_detections_f32, new entry points */
+#define TSOD_VERSION 210 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
+                            ticket area in the workspace), pitched tsod_detections_f32, new entry points;
+                            0.2.1: two more conv tiles (bf16x3 through LDS-DMA) */
 
 typedef void *tsod_stream_t; /* hipStream_t */
 
@@ -70,7 +71,9 @@ enum { TSOD_TILE_AUTO = 0, TSOD_TILE_128x128 = 1, TSOD_TILE_128x64 = 2, TSOD_TIL
        TSOD_TILE_128x128_W8 = 5, TSOD_TILE_128x64_W8 = 6, TSOD_TILE_256x128_W8 = 7, TSOD_TILE_64x64_S1 = 8,
        TSOD_TILE_128x64_W8_S1 = 9, TSOD_TILE_64x64_S1_K64 = 10, TSOD_TILE_128x64_W8_S1_K64 = 11,
        TSOD_TILE_64x64_W1_S1 = 12, TSOD_TILE_128x64_W2_S1 = 13, TSOD_TILE_128x64_S1 = 14, TSOD_TILE_64x128_S1 = 15,
-       TSOD_TILE_128x128_S1 = 16, TSOD_TILE_COUNT = 17 };
+       TSOD_TILE_128x128_S1 = 16,
+       /* bf16x3 only, fed by LDS-DMA (conv_dma_kernel): one channel segment, Cin a multiple of the K stage (16 / 32) */
+       TSOD_TILE_D128x128 = 17, TSOD_TILE_D64x128 = 18, TSOD_TILE_D256x128 = 19, TSOD_TILE_COUNT = 20 };
 /* arithmetic of the contraction.  F32: v_mfma_f32_32x32x2_f32 (a k-ordered f32 fma chain).  BF16X3: every f32 operand cut
  * exactly into three bf16 pieces (hi + mid + lo == x), six piece products per k accumulated in f32 on
  * v_mfma_f32_32x32x16_bf16: f32-level accuracy (error ~1.3e-7 of sum|a*b|) at 0.375x the matrix-pipe time; storage,

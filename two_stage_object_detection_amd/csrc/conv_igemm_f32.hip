@@ -127,6 +127,194 @@ __device__ __forceinline__ int seg_channel(const ConvParams &p, int ci) {
     return ch;
 }
 
+// ---- epilogue of one BM x BN tile held as 32x32 accumulator blocks, shared by every conv kernel of this file.
+// acc[i][j][e]: column = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (m) of block (i, j) of wave (wm, wn).
+// z < 0: whole tile (BN / PReLU / ReLU6 / residual, then the store); z >= 0: K-slice z (slab + ticket + last-arriver combine).
+// `smem`: at least (THREADS / 64) * 32 * kPatchLD floats of LDS that no wave reads any more.
+template <int BM, int BN, int WM, int WN, int THREADS>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[WM / 32][WN / 32], float *smem, int tid, int wm, int wn,
+                                              int m0, int n0, int z, int tile_id) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    const int lane = tid & 63, wave = tid >> 6;
+    // ---- epilogue.  acc[i][j][e]: column = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (m).
+    // All global accesses go through buffer descriptors: rows / columns outside the problem get the
+    // out-of-range offset, so there is no per-element branch (loads return 0, stores are dropped), and the
+    // 16 residual loads of a 32x32 tile are all in flight before the first one is consumed.
+    const int col_in = lane & 31;
+    const int row_in = 4 * (lane >> 5);
+    if (z >= 0) {
+        // K-slice: the whole BM x BN partial tile (zero rows / columns included) goes to this slice's own slab, then the
+        // slice that arrives LAST at the tile's ticket sums the slabs in slice order (fixed order -> bit-reproducible) and
+        // applies the epilogue: no second kernel, no launch boundary.  Hand-off between workgroups that may sit on different
+        // XCDs (private L2s): slabs are stored WRITE-THROUGH (sc1, 16 bytes per lane: each accumulator block goes through the
+        // wave's LDS patch so that a lane owns 4 consecutive columns), every storing wave drains its stores, one lane adds
+        // to the ticket at agent scope, and the reducer reads EVERY slab byte with sc1 loads (never through a stale L1/L2 line).
+        constexpr int AUX_SC1 = 16;
+        const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc((void *)p.partial, (short)0, (int)p.part_bytes, 0x00020000);
+        const int rem = tile_id - p.dp_tiles;
+        const unsigned slab0 = (unsigned)rem * (unsigned)p.split * (unsigned)(BM * BN * 4);   // byte offset of slice 0's slab
+        const unsigned my_slab = slab0 + (unsigned)z * (unsigned)(BM * BN * 4);
+        {
+            float *patch = smem + wave * (32 * kPatchLD);
+            const int pr = lane >> 3, pc = (lane & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + row_in) * kPatchLD + col_in] = acc[i][j][e];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float4 v = *reinterpret_cast<const float4 *>(patch + (pr + 8 * t) * kPatchLD + pc);
+                        const int rl = wm * WM + i * 32 + pr + 8 * t, cl = wn * WN + j * 32 + pc;
+                        u32x4 o;
+                        o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_part, my_slab + (unsigned)(rl * BN + cl) * 4u, 0, AUX_SC1);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next block overwrites it
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // EVERY storing wave drains its write-through stores
+        __syncthreads();
+        int *s_flag = reinterpret_cast<int *>(smem);                       // the one LDS array (patches are idle past the barrier)
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(p.tickets + rem, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == p.split - 1;
+            if (last) __hip_atomic_store(p.tickets + rem, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every slice has arrived
+            s_flag[0] = last;
+        }
+        __syncthreads();
+        if (s_flag[0] == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");             // no instruction: keeps the slab loads below the ticket
+        const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, (short)0, (int)p.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), (short)0,
+                                                                               (int)(p.res ? p.res_bytes : 0u), 0x00020000);
+        constexpr int QPR = BN / 4, QUADS = BM * BN / 4;
+        for (int q = tid; q < QUADS; q += THREADS) {
+            const unsigned qoff = slab0 + (unsigned)q * 16u;
+            float4 v = buffer_load4_aux<AUX_SC1>(rs_part, qoff);
+            int sl = 1;
+            for (; sl + 4 <= p.split; sl += 4) {                           // 4 slab loads in flight, added in slice order
+                float4 t4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t4[u] = buffer_load4_aux<AUX_SC1>(rs_part, qoff + (unsigned)(sl + u) * (unsigned)(BM * BN * 4));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v.x += t4[u].x; v.y += t4[u].y; v.z += t4[u].z; v.w += t4[u].w; }
+            }
+            for (; sl < p.split; ++sl) {
+                const float4 t1 = buffer_load4_aux<AUX_SC1>(rs_part, qoff + (unsigned)sl * (unsigned)(BM * BN * 4));
+                v.x += t1.x; v.y += t1.y; v.z += t1.z; v.w += t1.w;
+            }
+            const int m = m0 + q / QPR, n = n0 + (q % QPR) * 4;
+            if (m >= p.M || n >= p.Cout) continue;
+            float vv[4] = {v.x, v.y, v.z, v.w};
+            if (p.vec_epilogue) {                                          // Cout % 4 == 0: all four channels exist
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + n);
+                if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + n);
+                const float4 rs4 = buffer_load4(rs_r, p.res ? ((unsigned)m * (unsigned)p.res_pitch + (unsigned)(p.res_off + n)) * 4u : kOOB);
+                u32x4 o;
+                o.x = __float_as_uint(apply_act(vv[0] * sc.x + sh.x + rs4.x, p.neg_slope, p.act_hi));
+                o.y = __float_as_uint(apply_act(vv[1] * sc.y + sh.y + rs4.y, p.neg_slope, p.act_hi));
+                o.z = __float_as_uint(apply_act(vv[2] * sc.z + sh.z + rs4.z, p.neg_slope, p.act_hi));
+                o.w = __float_as_uint(apply_act(vv[3] * sc.w + sh.w + rs4.w, p.neg_slope, p.act_hi));
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u, 0, 0);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (n + c >= p.Cout) continue;
+                    float o = vv[c] * (p.scale ? p.scale[n + c] : 1.f) + (p.shift ? p.shift[n + c] : 0.f);
+                    if (p.res) o += p.res[(long)m * p.res_pitch + p.res_off + n + c];
+                    p.out[(long)m * p.out_pitch + p.out_off + n + c] = apply_act(o, p.neg_slope, p.act_hi);
+                }
+            }
+        }
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, (short)0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), (short)0,
+                                                                             (int)(p.res ? p.res_bytes : 0u), 0x00020000);
+    const bool has_res = p.res != nullptr;
+    if (p.vec_epilogue) {
+        // Wide epilogue: each 32x32 accumulator block is transposed through a wave-private LDS patch (the staging
+        // buffers are idle now) so that a lane owns 4 consecutive output channels: residual loads and output
+        // stores become dwordx4, 8 lanes per 128-byte row segment, 4x fewer VMEM instructions than the
+        // column-per-lane form.  Only LDS ops of this wave touch the patch: in-order LDS + lgkmcnt(0) orders them.
+        float *patch = smem + wave * (32 * kPatchLD);
+        const int pr = lane >> 3, pc = (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + pc;           // this lane's 4 output channels
+            const bool n_ok = n < p.Cout;                        // Cout % 4 == 0 on this path: all 4 or none
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.scale && n_ok) sc = *reinterpret_cast<const float4 *>(p.scale + n);
+            if (p.shift && n_ok) sh = *reinterpret_cast<const float4 *>(p.shift + n);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + row_in) * kPatchLD + col_in] = acc[i][j][e];
+                const int mb = m0 + wm * WM + i * 32 + pr;
+                float4 rs[4], v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int m = mb + 8 * t;
+                    const unsigned off = (m < p.M && n_ok && has_res)
+                                             ? ((unsigned)m * (unsigned)p.res_pitch + (unsigned)(p.res_off + n)) * 4u : kOOB;
+                    rs[t] = buffer_load4(rs_res, off);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const float4 *>(patch + (pr + 8 * t) * kPatchLD + pc);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int m = mb + 8 * t;
+                    const unsigned off = (m < p.M && n_ok) ? ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u : kOOB;
+                    u32x4 o;
+                    o.x = __float_as_uint(apply_act(v[t].x * sc.x + sh.x + rs[t].x, p.neg_slope, p.act_hi));
+                    o.y = __float_as_uint(apply_act(v[t].y * sc.y + sh.y + rs[t].y, p.neg_slope, p.act_hi));
+                    o.z = __float_as_uint(apply_act(v[t].z * sc.z + sh.z + rs[t].z, p.neg_slope, p.act_hi));
+                    o.w = __float_as_uint(apply_act(v[t].w * sc.w + sh.w + rs[t].w, p.neg_slope, p.act_hi));
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next block overwrites it
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + col_in;
+        const bool n_ok = n < p.Cout;
+        const float sc = (p.scale && n_ok) ? p.scale[n] : 1.f;
+        const float sh = (p.shift && n_ok) ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * WM + i * 32 + row_in;
+            float r[16];
+            if (has_res) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + (e & 3) + 8 * (e >> 2);
+                    const unsigned off = (m < p.M && n_ok) ? ((unsigned)m * (unsigned)p.res_pitch + (unsigned)(p.res_off + n)) * 4u : kOOB;
+                    r[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, off, 0, 0));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) r[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                const unsigned off = (m < p.M && n_ok) ? ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u : kOOB;
+                const float v = apply_act(acc[i][j][e] * sc + sh + r[e], p.neg_slope, p.act_hi);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, off, 0, 0);
+            }
+        }
+    }
+}
+
 // BM x BN workgroup tile, WM x WN per-wave tile: (BM/WM) x (BN/WN) waves of 64 lanes.
 // NBUF = 2: double-buffered LDS (the next K-step is staged under the MFMAs); NBUF = 1: one LDS buffer, the next
 // K-step waits in registers and is written between two barriers - half the LDS and fewer registers per workgroup,
@@ -515,182 +703,375 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
         g_clock_buf[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - diag_r0;
     }
 #endif
-    // ---- epilogue.  acc[i][j][e]: column = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (m).
-    // All global accesses go through buffer descriptors: rows / columns outside the problem get the
-    // out-of-range offset, so there is no per-element branch (loads return 0, stores are dropped), and the
-    // 16 residual loads of a 32x32 tile are all in flight before the first one is consumed.
-    const int col_in = lane & 31;
-    const int row_in = 4 * (lane >> 5);
-    if (z >= 0) {
-        // K-slice: the whole BM x BN partial tile (zero rows / columns included) goes to this slice's own slab, then the
-        // slice that arrives LAST at the tile's ticket sums the slabs in slice order (fixed order -> bit-reproducible) and
-        // applies the epilogue: no second kernel, no launch boundary.  Hand-off between workgroups that may sit on different
-        // XCDs (private L2s): slabs are stored WRITE-THROUGH (sc1, 16 bytes per lane: each accumulator block goes through the
-        // wave's LDS patch so that a lane owns 4 consecutive columns), every storing wave drains its stores, one lane adds
-        // to the ticket at agent scope, and the reducer reads EVERY slab byte with sc1 loads (never through a stale L1/L2 line).
-        constexpr int AUX_SC1 = 16;
-        const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc((void *)p.partial, (short)0, (int)p.part_bytes, 0x00020000);
-        const int rem = tile_id - p.dp_tiles;
-        const unsigned slab0 = (unsigned)rem * (unsigned)p.split * (unsigned)(BM * BN * 4);   // byte offset of slice 0's slab
-        const unsigned my_slab = slab0 + (unsigned)z * (unsigned)(BM * BN * 4);
-        {
-            float *patch = smem + wave * (32 * kPatchLD);
-            const int pr = lane >> 3, pc = (lane & 7) * 4;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + row_in) * kPatchLD + col_in] = acc[i][j][e];
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float4 v = *reinterpret_cast<const float4 *>(patch + (pr + 8 * t) * kPatchLD + pc);
-                        const int rl = wm * WM + i * 32 + pr + 8 * t, cl = wn * WN + j * 32 + pc;
-                        u32x4 o;
-                        o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_part, my_slab + (unsigned)(rl * BN + cl) * 4u, 0, AUX_SC1);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next block overwrites it
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // EVERY storing wave drains its write-through stores
-        __syncthreads();
-        int *s_flag = reinterpret_cast<int *>(smem);                       // the one LDS array (patches are idle past the barrier)
-        if (tid == 0) {
-            const int old = __hip_atomic_fetch_add(p.tickets + rem, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = old == p.split - 1;
-            if (last) __hip_atomic_store(p.tickets + rem, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every slice has arrived
-            s_flag[0] = last;
-        }
-        __syncthreads();
-        if (s_flag[0] == 0) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");             // no instruction: keeps the slab loads below the ticket
-        const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, (short)0, (int)p.out_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), (short)0,
-                                                                               (int)(p.res ? p.res_bytes : 0u), 0x00020000);
-        constexpr int QPR = BN / 4, QUADS = BM * BN / 4;
-        for (int q = tid; q < QUADS; q += THREADS) {
-            const unsigned qoff = slab0 + (unsigned)q * 16u;
-            float4 v = buffer_load4_aux<AUX_SC1>(rs_part, qoff);
-            int sl = 1;
-            for (; sl + 4 <= p.split; sl += 4) {                           // 4 slab loads in flight, added in slice order
-                float4 t4[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) t4[u] = buffer_load4_aux<AUX_SC1>(rs_part, qoff + (unsigned)(sl + u) * (unsigned)(BM * BN * 4));
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { v.x += t4[u].x; v.y += t4[u].y; v.z += t4[u].z; v.w += t4[u].w; }
-            }
-            for (; sl < p.split; ++sl) {
-                const float4 t1 = buffer_load4_aux<AUX_SC1>(rs_part, qoff + (unsigned)sl * (unsigned)(BM * BN * 4));
-                v.x += t1.x; v.y += t1.y; v.z += t1.z; v.w += t1.w;
-            }
-            const int m = m0 + q / QPR, n = n0 + (q % QPR) * 4;
-            if (m >= p.M || n >= p.Cout) continue;
-            float vv[4] = {v.x, v.y, v.z, v.w};
-            if (p.vec_epilogue) {                                          // Cout % 4 == 0: all four channels exist
-                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + n);
-                if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + n);
-                const float4 rs4 = buffer_load4(rs_r, p.res ? ((unsigned)m * (unsigned)p.res_pitch + (unsigned)(p.res_off + n)) * 4u : kOOB);
-                u32x4 o;
-                o.x = __float_as_uint(apply_act(vv[0] * sc.x + sh.x + rs4.x, p.neg_slope, p.act_hi));
-                o.y = __float_as_uint(apply_act(vv[1] * sc.y + sh.y + rs4.y, p.neg_slope, p.act_hi));
-                o.z = __float_as_uint(apply_act(vv[2] * sc.z + sh.z + rs4.z, p.neg_slope, p.act_hi));
-                o.w = __float_as_uint(apply_act(vv[3] * sc.w + sh.w + rs4.w, p.neg_slope, p.act_hi));
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u, 0, 0);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (n + c >= p.Cout) continue;
-                    float o = vv[c] * (p.scale ? p.scale[n + c] : 1.f) + (p.shift ? p.shift[n + c] : 0.f);
-                    if (p.res) o += p.res[(long)m * p.res_pitch + p.res_off + n + c];
-                    p.out[(long)m * p.out_pitch + p.out_off + n + c] = apply_act(o, p.neg_slope, p.act_hi);
-                }
-            }
-        }
-        return;
+    conv_epilogue<BM, BN, WM, WN, THREADS>(p, acc, smem, tid, wm, wn, m0, n0, z, tile_id);
+}
+
+// =====================================================================================================================
+// bf16x3 convolution fed by LDS-DMA (gfx950 `buffer_load_dwordx4 ... offen lds`): no VGPR staging, no ds_write, every
+// instruction of the K loop a pinned asm statement.  What the register-staged kernel above loses at low occupancy is issue
+// order (an LDS-read burst, a split burst and a DMA burst in front of the MFMAs of each K-step); here the order is the
+// source order:  barrier -> {MFMAs of stage p | LDS reads of stage p+1 | split of stage p+1's A fragment | DMA of stage p+S}.
+//   * A (activations, f32) lands in LDS RAW: rows of BK floats, the 16-byte slots of a row XOR-swizzled through the per-lane
+//     SOURCE address (an LDS-DMA writes lane i at base + 16 i, so the swizzle can only be applied on the source side).  The
+//     im2col gather is that same per-lane source address; padding taps and rows >= M use the out-of-range offset, for which
+//     the DMA writes zeros (scripts/micro/lds_dma_oob.hip).  The wave that OWNS a fragment splits it into the three bf16
+//     pieces, in the shadow of its own MFMAs: no element is split twice, and there are 44 VALU per 24 MFMAs.
+//   * B (weights) is the pre-split image of tsod_pack_conv_weight_bf16x3 and lands in three unpadded planes.
+//   * Wave tile 32 x 128 (BN = 128): WAVES_M = BM / 32 waves along M, and for the small tile WAVES_K = 2 waves along K
+//     inside a stage (each owns one 16-k chunk; the halves are exchanged through LDS before the epilogue, every wave then
+//     finishing 32 x 64).  One phase per stage and wave; an S-deep ring of stages; vmcnt / lgkmcnt counted by hand (the
+//     compiler sees none of these memory operations; what it must not do is keep LDS reads of its own pending in the loop).
+// Requires one channel segment, Cin % BK == 0 (a stage lies inside one filter tap) and, with a second source, K1 % BK == 0.
+// Measurements and the instruction-level findings behind this layout: DESIGN.md 4.3, scripts/micro/bf16x3_dma_probe.hip.
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v4i32 dma_rsrc(const void *ptr, unsigned bytes) {
+    v4i32 r; const unsigned long long a = (unsigned long long)ptr;
+    r[0] = (int)(unsigned)a; r[1] = (int)((unsigned)(a >> 32) & 0xffff); r[2] = (int)bytes; r[3] = 0x00020000;
+    return r;
+}
+// one wave-instruction: 64 lanes x 16 bytes from per-lane source offsets to LDS [lds_dst, lds_dst + 1024)
+__device__ __forceinline__ void dma16(unsigned voff, v4i32 rsrc, unsigned soff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); }
+template <int OFF, typename T> __device__ __forceinline__ void lds_read16(T &out, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(out) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void mfma_bf16(f32x16 &c, const bf16x8 &a, const bf16x8 &b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// One MFMA gap = ONE asm statement (the compiler pads every boundary between two asm statements that share a register with a
+// conservative s_nop, so the fewer boundaries the better; inside a statement the order and the spacing are ours):
+//   gap_cvt:  MFMA; pk = rne_bf16x2(x0, x1); t0 = f32(pk.lo); t1 = f32(pk.hi)
+//   gap_sub:  MFMA; r0 = x0 - t0; r1 = x1 - t1 (exact); one LDS fragment read of the next stage
+//   gap_last: MFMA; pk = rne_bf16x2(x0, x1)
+__device__ __forceinline__ void gap_cvt(f32x16 &c, const bf16x8 &a, const bf16x8 &b, float x0, float x1, unsigned &pk, float &t0, float &t1) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\t"
+                 "v_cvt_pk_bf16_f32 %1, %6, %7\n\t"
+                 "v_lshlrev_b32 %2, 16, %1\n\t"
+                 "v_and_b32 %3, 0xffff0000, %1"
+                 : "+v"(c), "=&v"(pk), "=&v"(t0), "=&v"(t1) : "v"(a), "v"(b), "v"(x0), "v"(x1));
+}
+template <int OFF, typename T>
+__device__ __forceinline__ void gap_sub(f32x16 &c, const bf16x8 &a, const bf16x8 &b, float &r0, float &r1, float x0, float x1, float t0, float t1,
+                                        T &rd, unsigned addr) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\t"
+                 "v_sub_f32 %1, %6, %8\n\t"
+                 "v_sub_f32 %2, %7, %9\n\t"
+                 "ds_read_b128 %3, %10 offset:%11"
+                 : "+v"(c), "=&v"(r0), "=&v"(r1), "=&v"(rd) : "v"(a), "v"(b), "v"(x0), "v"(x1), "v"(t0), "v"(t1), "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void gap_last(f32x16 &c, const bf16x8 &a, const bf16x8 &b, float x0, float x1, unsigned &pk) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\t"
+                 "v_cvt_pk_bf16_f32 %1, %4, %5"
+                 : "+v"(c), "=&v"(pk) : "v"(a), "v"(b), "v"(x0), "v"(x1));
+}
+template <int OFF, typename T>
+__device__ __forceinline__ void gap_read(f32x16 &c, const bf16x8 &a, const bf16x8 &b, T &rd, unsigned addr) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\t"
+                 "ds_read_b128 %1, %4 offset:%5"
+                 : "+v"(c), "=&v"(rd) : "v"(a), "v"(b), "v"(addr), "n"(OFF) : "memory");
+}
+
+constexpr int dma_stage_bytes(int bm, int bk) { return bm * bk * 4 + 3 * 128 * bk * 2; }
+
+template <int BM, int BK, int WAVES_K, int S>
+__global__ void __launch_bounds__((BM / 32) * WAVES_K * 64, (2 * S * dma_stage_bytes(BM, BK) <= 160 * 1024) ? 2 : 1)
+conv_dma_kernel(const ConvParams p) {
+    constexpr int BN = 128, TN = 4, WAVES_M = BM / 32, WAVES = WAVES_M * WAVES_K, THREADS = WAVES * 64;
+    static_assert(BK == 16 * WAVES_K, "every wave owns one 16-k chunk of the stage");
+    constexpr int A_ROW = BK * 4, B_ROW = BK * 2;                    // bytes per LDS row (A raw f32 / one bf16 plane of B)
+    constexpr int A_SLOTS = A_ROW / 16, B_SLOTS = B_ROW / 16;        // 16-byte slots per row
+    constexpr int A_RPL = 256 / A_ROW, B_RPL = 256 / B_ROW;          // rows per 256-byte bank line: slot ^= (row / RPL) & (SLOTS - 1)
+    constexpr int A_BYTES = BM * A_ROW, B_PLANE = BN * B_ROW, STAGE = dma_stage_bytes(BM, BK);
+    constexpr int A_RPP = 1024 / A_ROW, B_RPP = 1024 / B_ROW;        // rows per 1-KiB DMA piece
+    constexpr int A_PIECES = BM / A_RPP, B_PIECES = 3 * (BN / B_RPP);
+    static_assert(A_PIECES % WAVES == 0, "piece kinds per wave at compile time");
+    // this wave's A pieces / all its pieces per stage; when the B pieces do not divide by the waves the last ones are
+    // padding (an out-of-range source: zeros into a scratch KiB behind the stage), so that every wave counts the same vmcnt
+    constexpr int PA_W = A_PIECES / WAVES, PB_W = (B_PIECES + WAVES - 1) / WAVES, P = PA_W + PB_W;
+    constexpr bool B_PAD = B_PIECES % WAVES != 0;
+    constexpr int PATCHES = WAVES * 32 * kPatchLD * 4;
+    static_assert(S * STAGE >= PATCHES && S * STAGE >= WAVES * 2 * 16 * 64 * 4, "epilogue patches / K-half exchange fit the ring");
+    __shared__ __align__(16) unsigned char lds[S * STAGE + (B_PAD ? 1024 : 0)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WAVES_M, wk = wave / WAVES_M;
+    int tile_id, z;
+    if ((int)blockIdx.x < p.dp_tiles) {                               // same workgroup -> work map as conv_igemm_kernel
+        const int nwg = p.dp_tiles;
+        const int q = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+        tile_id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (blockIdx.x >> 3);
+        z = -1;
+    } else {
+        const int r = blockIdx.x - p.dp_tiles;
+        tile_id = p.dp_tiles + r / p.split;
+        z = r % p.split;
     }
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, (short)0, (int)p.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), (short)0,
-                                                                             (int)(p.res ? p.res_bytes : 0u), 0x00020000);
-    const bool has_res = p.res != nullptr;
-    if (p.vec_epilogue) {
-        // Wide epilogue: each 32x32 accumulator block is transposed through a wave-private LDS patch (the staging
-        // buffers are idle now) so that a lane owns 4 consecutive output channels: residual loads and output
-        // stores become dwordx4, 8 lanes per 128-byte row segment, 4x fewer VMEM instructions than the
-        // column-per-lane form.  Only LDS ops of this wave touch the patch: in-order LDS + lgkmcnt(0) orders them.
-        float *patch = smem + wave * (32 * kPatchLD);
-        const int pr = lane >> 3, pc = (lane & 7) * 4;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 32 + pc;           // this lane's 4 output channels
-            const bool n_ok = n < p.Cout;                        // Cout % 4 == 0 on this path: all 4 or none
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.scale && n_ok) sc = *reinterpret_cast<const float4 *>(p.scale + n);
-            if (p.shift && n_ok) sh = *reinterpret_cast<const float4 *>(p.shift + n);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + row_in) * kPatchLD + col_in] = acc[i][j][e];
-                const int mb = m0 + wm * WM + i * 32 + pr;
-                float4 rs[4], v[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int m = mb + 8 * t;
-                    const unsigned off = (m < p.M && n_ok && has_res)
-                                             ? ((unsigned)m * (unsigned)p.res_pitch + (unsigned)(p.res_off + n)) * 4u : kOOB;
-                    rs[t] = buffer_load4(rs_res, off);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const float4 *>(patch + (pr + 8 * t) * kPatchLD + pc);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int m = mb + 8 * t;
-                    const unsigned off = (m < p.M && n_ok) ? ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u : kOOB;
-                    u32x4 o;
-                    o.x = __float_as_uint(apply_act(v[t].x * sc.x + sh.x + rs[t].x, p.neg_slope, p.act_hi));
-                    o.y = __float_as_uint(apply_act(v[t].y * sc.y + sh.y + rs[t].y, p.neg_slope, p.act_hi));
-                    o.z = __float_as_uint(apply_act(v[t].z * sc.z + sh.z + rs[t].z, p.neg_slope, p.act_hi));
-                    o.w = __float_as_uint(apply_act(v[t].w * sc.w + sh.w + rs[t].w, p.neg_slope, p.act_hi));
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next block overwrites it
-            }
+    const int tn_i = tile_id % p.tiles_n, tm_i = tile_id / p.tiles_n;
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const int kt_begin = z < 0 ? 0 : z * p.ksteps_per_split;
+    const int kt_end = z < 0 ? p.ksteps : min(p.ksteps, kt_begin + p.ksteps_per_split);
+    const int nk = kt_end - kt_begin;
+
+    const v4i32 rs_in = dma_rsrc(p.in, p.in_bytes), rs_w = dma_rsrc(p.w, p.w_bytes);
+    const v4i32 rs_in2 = dma_rsrc(p.in2 ? p.in2 : p.in, p.in2 ? p.in2_bytes : 0u);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)lds;
+    const int kgroups = p.K / 8;
+
+    // ---- this wave's DMA pieces: q = WAVES * i + wave; piece i is an A piece for i < PA_W (= 2 for both tile shapes; the two
+    // rows' state in two named structs: an array of them ends up in scratch memory behind the source select below, and a
+    // scratch access is a VMEM operation that would sit in the middle of the hand-counted vmcnt)
+    static_assert(PA_W == 2, "two A pieces per wave and stage");
+    struct ARow { unsigned base, base2; int ih0, iw0; };
+    unsigned b_voff[P - PA_W], ldst[P];
+    auto make_arow = [&](int i) {
+        ARow ar;
+        const int q = WAVES * i + wave;
+        const int row = q * A_RPP + lane / A_SLOTS, phys = lane % A_SLOTS;
+        const unsigned lofs = (unsigned)((phys ^ ((row / A_RPL) & (A_SLOTS - 1))) * 16);
+        const int m = m0 + row;
+        if (m < p.M) {
+            const int ow = m % p.OW, t = m / p.OW, oh = t % p.OH, img = t / p.OH;
+            ar.ih0 = oh * p.stride - p.pad_h;
+            ar.iw0 = ow * p.stride - p.pad_w;
+            // may wrap below zero for border rows; adding a valid tap's delta brings it back in range
+            ar.base = (unsigned)((((long)img * p.H + ar.ih0) * p.W + ar.iw0) * p.in_pitch + p.seg_off[0]) * 4u + lofs;
+            ar.base2 = p.c2 > 0 ? (unsigned)((((long)img * p.H2 + oh * p.stride2) * p.W2 + ow * p.stride2) * p.in2_pitch + p.in2_off) * 4u + lofs
+                                : kOOB;
+        } else {
+            ar.ih0 = INT_MIN / 2; ar.iw0 = INT_MIN / 2; ar.base = 0; ar.base2 = kOOB;
         }
-        return;
+        return ar;
+    };
+    const ARow ar0 = make_arow(0), ar1 = make_arow(1);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int q = WAVES * i + wave;
+        if (i < PA_W) {
+            ldst[i] = q * 1024;
+        } else {
+            const int qb = WAVES * (i - PA_W) + wave, plane = qb / (BN / B_RPP), rb = qb % (BN / B_RPP);
+            const int row = rb * B_RPP + lane / B_SLOTS, phys = lane % B_SLOTS, logical = phys ^ ((row / B_RPL) & (B_SLOTS - 1));
+            const int n = n0 + row;
+            const bool real = qb < B_PIECES;
+            b_voff[i - PA_W] = (real && n < p.Cout) ? ((unsigned)n * (unsigned)kgroups + (unsigned)logical) * 48u + (unsigned)plane * 16u : kOOB;
+            ldst[i] = real ? A_BYTES + plane * B_PLANE + rb * 1024 : S * STAGE;
+        }
+        ldst[i] = __builtin_amdgcn_readfirstlane(ldst[i] + lds0);
+    }
+    // State of the stage being ISSUED, all wave-uniform (scalar unit): its K-step, filter tap, channel base, the byte offset
+    // that tap adds to a pixel's base address, which source it reads and the two descriptors (zero records once the stage lies
+    // past this workgroup's K range: a null DMA, no memory traffic, zeros written, so that the counted waits never change).
+    int u_kt = kt_begin, u_kh, u_kw, u_ci;
+    {
+        const int kb = kt_begin * BK, seg0 = kb / p.Cin;
+        u_ci = kb - seg0 * p.Cin;
+        u_kh = seg0 / p.KW;
+        u_kw = seg0 - u_kh * p.KW;
+    }
+    unsigned u_delta, u_woff;
+    bool u_second;
+    v4i32 u_rs_a, u_rs_w;
+    auto stage_state = [&]() {
+        const bool live = u_kt < kt_end;
+        u_second = u_kt * BK >= p.K1;                             // second source: a 1x1 tap, always inside the image
+        u_delta = u_second ? (unsigned)((u_kt * BK - p.K1) * 4) : (unsigned)(((u_kh * p.W + u_kw) * p.in_pitch + u_ci) * 4);
+        u_woff = (unsigned)(u_kt * (BK / 8) * 48);
+        // (readfirstlane: the divergence analysis loses sight of the uniformity of this loop-carried state, and a descriptor
+        //  must sit in scalar registers)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            u_rs_a[c] = __builtin_amdgcn_readfirstlane(c == 2 && !live ? 0 : (u_second ? rs_in2[c] : rs_in[c]));
+            u_rs_w[c] = __builtin_amdgcn_readfirstlane(c == 2 && !live ? 0 : rs_w[c]);
+        }
+        u_delta = (unsigned)__builtin_amdgcn_readfirstlane((int)u_delta);
+        u_woff = (unsigned)__builtin_amdgcn_readfirstlane((int)u_woff);
+    };
+    stage_state();
+    auto advance_stage = [&]() {
+        ++u_kt;
+        u_ci += BK;
+        if (u_ci >= p.Cin) { u_ci = 0; if (++u_kw == p.KW) { u_kw = 0; ++u_kh; } }
+        stage_state();
+    };
+    // piece I of the stage being issued into ring slot `slot` (branch-free: selects only; I is a compile-time constant so
+    // that the per-piece state stays in registers)
+    auto issue_piece = [&](auto I, int slot) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i < PA_W) {
+            const ARow ar = i == 0 ? ar0 : ar1;
+            const int ih = ar.ih0 + u_kh, iw = ar.iw0 + u_kw;
+            const bool ok1 = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            // (second source: rows >= M carry the out-of-range base, plus a delta it may wrap into the tensor: such rows read
+            //  real bytes instead of zeros, which is harmless - they feed output rows that are never stored)
+            const unsigned v1 = ok1 ? ar.base + u_delta : kOOB, v2 = ar.base2 + u_delta;
+            dma16(u_second ? v2 : v1, u_rs_a, 0u, ldst[i] + slot * STAGE);
+        } else {
+            // (a padding piece has the out-of-range source everywhere; its destination is the scratch KiB behind the ring, which
+            //  the slot offset must not move: ldst - lds0 == S * STAGE marks it)
+            const unsigned dst = (B_PAD && ldst[i] - lds0 == (unsigned)(S * STAGE)) ? ldst[i] : ldst[i] + slot * STAGE;
+            dma16(b_voff[i - PA_W], u_rs_w, u_woff, dst);
+        }
+    };
+
+    f32x16 acc[1][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
+
+    // fragment addresses inside a stage: lane (h, r) holds k = 16 wk + 8 h .. + 7 of row r
+    const int h = lane >> 5, r = lane & 31;
+    unsigned a_addr[2], b_addr[TN];
+    {
+        const int row = wm * 32 + r, s0 = wk * 4 + 2 * h, sw = (row / A_RPL) & (A_SLOTS - 1);
+        a_addr[0] = lds0 + row * A_ROW + ((s0 ^ sw) * 16);
+        a_addr[1] = lds0 + row * A_ROW + (((s0 + 1) ^ sw) * 16);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + col_in;
-        const bool n_ok = n < p.Cout;
-        const float sc = (p.scale && n_ok) ? p.scale[n] : 1.f;
-        const float sh = (p.shift && n_ok) ? p.shift[n] : 0.f;
+        const int row = j * 32 + r, sl = wk * 2 + h, sw = (row / B_RPL) & (B_SLOTS - 1);
+        b_addr[j] = lds0 + A_BYTES + row * B_ROW + ((sl ^ sw) * 16);
+    }
+
+    struct Frags { bf16x8 a[3], b[TN][3]; };
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // product q = A piece PA[q] x B piece PB[q] (smallest first)
+
+    // One phase.  MFMA n = 4 q + j (product q, accumulator j) runs on `cur`; the 14 LDS reads of the next stage go out in the
+    // first gaps (A raw first), its A fragment is split behind MFMAs 4..23 (one pair per five MFMAs: h = rne(x); x -= h;
+    // m = rne(x); x -= m; l = rne(x); at most 3 VALU per MFMA gap, which is what issues in an MFMA's shadow), and this
+    // wave's DMA pieces of the stage being issued go out one per few gaps.  `soff` = byte offset of the ring slot that is read.
+    auto phase = [&](const Frags &cur, Frags &nxt, unsigned soff, int dma_slot) {
+        float4 raw0, raw1;
+        unsigned hh[4], mm[4], ll[4];
+        float t0, t1, r0, r1, q0, q1;
+#define TSOD_DMA(I) do { if constexpr ((I) < P) issue_piece(std::integral_constant<int, (I)>{}, dma_slot); } while (0)
+#define TSOD_MF(n) acc[0][(n) & 3], cur.a[PA[(n) >> 2]], cur.b[(n) & 3][PB[(n) >> 2]]
+        lds_read16<0>(raw0, a_addr[0] + soff);
+        lds_read16<0>(raw1, a_addr[1] + soff);
+        gap_read<0 * B_PLANE>(TSOD_MF(0), nxt.b[0][0], b_addr[0] + soff);
+        gap_read<0 * B_PLANE>(TSOD_MF(1), nxt.b[1][0], b_addr[1] + soff);
+        gap_read<0 * B_PLANE>(TSOD_MF(2), nxt.b[2][0], b_addr[2] + soff);
+        gap_read<0 * B_PLANE>(TSOD_MF(3), nxt.b[3][0], b_addr[3] + soff);
+        TSOD_DMA(0);
+        wait_lgkm<4>();                                         // raw0, raw1 have landed (four younger reads may be out)
+#define TSOD_SPLIT_GROUP(N0, X0, X1, G, PL, J0, J1)                                                        \
+        gap_cvt(TSOD_MF(N0), X0, X1, hh[G], t0, t1);                                                       \
+        gap_sub<PL * B_PLANE>(TSOD_MF(N0 + 1), r0, r1, X0, X1, t0, t1, nxt.b[J0][PL], b_addr[J0] + soff);  \
+        gap_cvt(TSOD_MF(N0 + 2), r0, r1, mm[G], t0, t1);                                                   \
+        if constexpr (P > 5) TSOD_DMA(1 + 2 * G);                                                          \
+        gap_sub<PL * B_PLANE>(TSOD_MF(N0 + 3), q0, q1, r0, r1, t0, t1, nxt.b[J1][PL], b_addr[J1] + soff);  \
+        gap_last(TSOD_MF(N0 + 4), q0, q1, ll[G]);                                                          \
+        if constexpr (P > 5) TSOD_DMA(2 + 2 * G); else TSOD_DMA(1 + G);
+        TSOD_SPLIT_GROUP(4, raw0.x, raw0.y, 0, 2, 0, 1)
+        TSOD_SPLIT_GROUP(9, raw0.z, raw0.w, 1, 2, 2, 3)
+        TSOD_SPLIT_GROUP(14, raw1.x, raw1.y, 2, 1, 0, 1)
+        TSOD_SPLIT_GROUP(19, raw1.z, raw1.w, 3, 1, 2, 3)
+#undef TSOD_MF
+#undef TSOD_SPLIT_GROUP
+        static_assert(P <= 9, "DMA slots of a phase");
+        advance_stage();
+        nxt.a[0] = __builtin_bit_cast(bf16x8, (u32x4{hh[0], hh[1], hh[2], hh[3]}));
+        nxt.a[1] = __builtin_bit_cast(bf16x8, (u32x4{mm[0], mm[1], mm[2], mm[3]}));
+        nxt.a[2] = __builtin_bit_cast(bf16x8, (u32x4{ll[0], ll[1], ll[2], ll[3]}));
+    };
+    // next stage visible to every wave; the ring slot of the stage that is now in registers may be refilled
+    auto turn = [&]() {
+        wait_vm<(S - 2) * P>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    if (nk > 0) {
+        // prologue: every ring slot filled (stages kt_begin .. kt_begin + S - 1), stage 0 visible, its fragments in X
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * WM + i * 32 + row_in;
-            float r[16];
-            if (has_res) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mb + (e & 3) + 8 * (e >> 2);
-                    const unsigned off = (m < p.M && n_ok) ? ((unsigned)m * (unsigned)p.res_pitch + (unsigned)(p.res_off + n)) * 4u : kOOB;
-                    r[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, off, 0, 0));
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) r[e] = 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                const unsigned off = (m < p.M && n_ok) ? ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u : kOOB;
-                const float v = apply_act(acc[i][j][e] * sc + sh + r[e], p.neg_slope, p.act_hi);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, off, 0, 0);
-            }
+        for (int s = 0; s < S; ++s) {
+            const int dma_slot = s;
+            TSOD_DMA(0); TSOD_DMA(1); TSOD_DMA(2); TSOD_DMA(3); TSOD_DMA(4); TSOD_DMA(5); TSOD_DMA(6); TSOD_DMA(7); TSOD_DMA(8);
+            advance_stage();
         }
+        wait_vm<(S - 1) * P>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        Frags X, Y;
+        {
+            const float4 raw0 = *reinterpret_cast<const float4 *>(lds + (a_addr[0] - lds0));
+            const float4 raw1 = *reinterpret_cast<const float4 *>(lds + (a_addr[1] - lds0));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) X.b[j][pl] = *reinterpret_cast<const bf16x8 *>(lds + (b_addr[j] - lds0) + pl * B_PLANE);
+            unsigned hh[4], mm[4], ll[4];
+            split3_pair(raw0.x, raw0.y, hh[0], mm[0], ll[0]);
+            split3_pair(raw0.z, raw0.w, hh[1], mm[1], ll[1]);
+            split3_pair(raw1.x, raw1.y, hh[2], mm[2], ll[2]);
+            split3_pair(raw1.z, raw1.w, hh[3], mm[3], ll[3]);
+            X.a[0] = __builtin_bit_cast(bf16x8, (u32x4{hh[0], hh[1], hh[2], hh[3]}));
+            X.a[1] = __builtin_bit_cast(bf16x8, (u32x4{mm[0], mm[1], mm[2], mm[3]}));
+            X.a[2] = __builtin_bit_cast(bf16x8, (u32x4{ll[0], ll[1], ll[2], ll[3]}));
+            // the compiler must finish its own LDS reads HERE: with one pending at the loop head it puts a conservative
+            // lgkmcnt(0) in front of the first MFMA of every iteration
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(X.b[j][pl]));
+        }
+        // phase i: MFMAs of stage i, LDS reads of stage i+1 (slot (i+1) % S), DMA of stage i+S into slot i % S
+        int slot = 0;
+        auto next = [&](int s) { return s + 1 == S ? 0 : s + 1; };
+        int i = 0;
+        for (; i + 1 < nk; i += 2) {
+            turn();
+            const int s1 = next(slot), s2 = next(s1);
+            phase(X, Y, (unsigned)(s1 * STAGE), slot);
+            turn();
+            phase(Y, X, (unsigned)(s2 * STAGE), s1);
+            slot = s2;
+        }
+        if (i < nk) {                                            // odd count: one more phase (its reads fetch a null stage)
+            turn();
+            phase(X, Y, (unsigned)(next(slot) * STAGE), slot);
+        }
+        wait_vm<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // asm-issued MFMA results -> ordinary reads
+    }
+#undef TSOD_DMA
+    __syncthreads();                                             // no wave reads the ring any more: the epilogue may use it
+    float *smem = reinterpret_cast<float *>(lds);
+    if constexpr (WAVES_K == 2) {
+        // the two K halves of a 32 x 128 stripe sit in waves (wm, 0) and (wm, 1): each keeps the 64 columns [64 wk, 64 wk + 64),
+        // hands the other 64 over through LDS ([wave][block][e][lane], lane-contiguous) and adds what its partner handed over
+        f32x16 acc2[1][2];
+        const int partner = wm + WAVES_M * (1 - wk);
+        if (wk == 0) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) smem[((wave * 2 + b) * 16 + e) * 64 + lane] = acc[0][2 + b][e];
+        } else {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) smem[((wave * 2 + b) * 16 + e) * 64 + lane] = acc[0][b][e];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[0][b][e] = acc[0][b][e] + smem[((partner * 2 + b) * 16 + e) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[0][b][e] = smem[((partner * 2 + b) * 16 + e) * 64 + lane] + acc[0][2 + b][e];
+        }
+        __syncthreads();
+        conv_epilogue<BM, BN, 32, 64, THREADS>(p, acc2, smem, tid, wm, wk, m0, n0, z, tile_id);
+    } else {
+        conv_epilogue<BM, BN, 32, 128, THREADS>(p, acc, smem, tid, wm, 0, m0, n0, z, tile_id);
     }
 }
 
@@ -737,20 +1118,22 @@ pack_weight_bf16x3_kernel(const float *__restrict__ w, int Cout, int K, unsigned
     }
 }
 
-struct TileInfo { int bm, bn, threads, resident; float cost; int bk, nbuf, bf16x3; };   // resident = workgroups per CU (LDS / VGPR bound)
+// resident = workgroups per CU (LDS / VGPR bound); dma = 1: conv_dma_kernel (bf16x3 only, nbuf = ring stages)
+struct TileInfo { int bm, bn, threads, resident; float cost; int bk, nbuf, bf16x3, dma; };
 const TileInfo kTiles[TSOD_TILE_COUNT] = {
     {0, 0, 0, 0, 0.f, 32, 2, 0},        {128, 128, 256, 2, 1.00f, 32, 2, 0}, {128, 64, 256, 2, 1.06f, 32, 2, 0}, {64, 64, 256, 4, 1.15f, 32, 2, 1},
     {64, 128, 256, 2, 1.06f, 32, 2, 0}, {128, 128, 512, 2, 1.00f, 32, 2, 0}, {128, 64, 512, 2, 1.06f, 32, 2, 0}, {256, 128, 512, 1, 0.98f, 32, 2, 0},
     {64, 64, 256, 6, 1.20f, 32, 1, 1},  {128, 64, 512, 3, 1.10f, 32, 1, 1},  {64, 64, 256, 4, 1.10f, 64, 1, 1},  {128, 64, 512, 2, 1.05f, 64, 1, 0},
     {64, 64, 64, 8, 1.40f, 32, 1, 0},   {128, 64, 128, 4, 1.35f, 32, 1, 0}, {128, 64, 256, 4, 1.12f, 32, 1, 1}, {64, 128, 256, 4, 1.12f, 32, 1, 1},
-    {128, 128, 256, 2, 1.02f, 32, 1, 1}};
+    {128, 128, 256, 2, 1.02f, 32, 1, 1},
+    {128, 128, 256, 2, 0.80f, 16, 4, 1, 1}, {64, 128, 256, 1, 0.95f, 32, 3, 1, 1}, {256, 128, 512, 1, 0.72f, 16, 4, 1, 1}};
 // bf16x3 = 1: the tile also exists as a bf16x3 variant (three bf16 planes per operand fit the 64 KB of static LDS)
 
 // workgroups per CU: the f32 figure (VGPR / LDS bound), for bf16x3 additionally capped by its larger LDS footprint
 int residency(int tile, int prec) {
     const TileInfo &t = kTiles[tile];
     if (!prec) return t.resident;
-    const int lds = t.nbuf * 3 * (t.bm + t.bn) * (t.bk / 2) * 4;
+    const int lds = t.dma ? t.nbuf * dma_stage_bytes(t.bm, t.bk) : t.nbuf * 3 * (t.bm + t.bn) * (t.bk / 2) * 4;
     const int fit = 160 * 1024 / lds;
     return fit < t.resident ? (fit < 1 ? 1 : fit) : t.resident;
 }
@@ -774,6 +1157,7 @@ int validate(const tsod_conv2d_desc *d) {
     TSOD_REQUIRE(d->tile >= 0 && d->tile < TSOD_TILE_COUNT && d->split_k >= -1 && d->split_k <= 64, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->precision == TSOD_PREC_BF16X3, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->tile == TSOD_TILE_AUTO || kTiles[d->tile].bf16x3, TSOD_ERR_UNSUPPORTED);
+    TSOD_REQUIRE(d->precision == TSOD_PREC_BF16X3 || d->tile == TSOD_TILE_AUTO || !kTiles[d->tile].dma, TSOD_ERR_UNSUPPORTED);
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
     TSOD_REQUIRE(M < (int64_t)INT_MAX, TSOD_ERR_UNSUPPORTED);
     if (d->c2 != 0) {                                   // second source: a strided 1x1 tap of another tensor
@@ -796,8 +1180,12 @@ int desc_cin(const tsod_conv2d_desc *d) {
 // contraction length: the filter taps over the first source + the second source's channels
 int desc_k(const tsod_conv2d_desc *d) { return d->KH * d->KW * desc_cin(d) + (d->c2 > 0 ? d->c2 : 0); }
 
-// a tile's K-step must divide both the channel count (uniform taps) and K1 when there is a second source
-bool tile_ok_for(const tsod_conv2d_desc *d, int bk) {
+// a tile's K-step must divide both the channel count (uniform taps) and K1 when there is a second source; the LDS-DMA
+// tiles need that always (a stage lies inside one filter tap of one channel segment, K is whole stages)
+bool tile_ok_for(const tsod_conv2d_desc *d, int tile) {
+    const int bk = kTiles[tile].bk;
+    if (kTiles[tile].dma)
+        return d->n_seg == 1 && desc_cin(d) % bk == 0 && (d->c2 <= 0 || d->c2 % bk == 0);
     if (d->c2 <= 0) return true;
     return desc_cin(d) % bk == 0 && (d->KH * d->KW * desc_cin(d)) % bk == 0;
 }
@@ -884,7 +1272,8 @@ Sched resolve(const tsod_conv2d_desc *d) {
     for (int t = 1; t < TSOD_TILE_COUNT; ++t) {
         if (d->tile != TSOD_TILE_AUTO && d->tile != t) continue;
         if (d->precision && !kTiles[t].bf16x3) continue;
-        if (!tile_ok_for(d, kTiles[t].bk) && d->tile != t) continue;
+        if (!d->precision && kTiles[t].dma) continue;
+        if (!tile_ok_for(d, t) && (d->tile != t || kTiles[t].dma)) continue;
         if (d->split_k != 0) {
             const Sched s = make_sched(d, t, d->split_k);
             if (s.cost < best.cost) best = s;
@@ -901,6 +1290,11 @@ Sched resolve(const tsod_conv2d_desc *d) {
     return best;
 }
 
+template <int BM, int BK, int WAVES_K, int S>
+void launch_dma_tile(const ConvParams &p, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S>), dim3(grid), dim3((BM / 32) * WAVES_K * 64), 0, s, p);
+}
+
 template <int BM, int BN, int WM, int WN, int MW, int NBUF = 2, int BK = 32, int PREC = 0>
 void launch_tile(const ConvParams &p, int grid, hipStream_t s) {
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MW, NBUF, BK, PREC>), dim3(grid), dim3(64 * (BM / WM) * (BN / WN)), 0, s, p);
@@ -913,6 +1307,7 @@ extern "C" int tsod_conv2d_resolve(const tsod_conv2d_desc *d, int32_t *tile, int
     if (rc != TSOD_OK) return rc;
     TSOD_REQUIRE(tile && split_k, TSOD_ERR_INVALID_ARG);
     const Sched s = resolve(d);
+    TSOD_REQUIRE(s.cost < 1e299, TSOD_ERR_UNSUPPORTED);
     *tile = s.tile;
     *split_k = s.rem_tiles == 0 ? 1 : (s.dp_tiles == 0 ? s.split : -1);
     return TSOD_OK;
@@ -920,7 +1315,8 @@ extern "C" int tsod_conv2d_resolve(const tsod_conv2d_desc *d, int32_t *tile, int
 
 extern "C" size_t tsod_conv2d_workspace_bytes(const tsod_conv2d_desc *d) {
     if (validate(d) != TSOD_OK) return 0;
-    return resolve(d).ws_bytes;
+    const Sched s = resolve(d);
+    return s.cost < 1e299 ? s.ws_bytes : 0;
 }
 
 extern "C" int tsod_conv2d_f32(const tsod_conv2d_desc *d, const float *in, const float *w_packed, const float *scale,
@@ -986,6 +1382,7 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
         p.inv_kw = 1.0f / (float)d->KW;
     }
     const Sched sc = resolve(d);
+    TSOD_REQUIRE(sc.cost < 1e299, TSOD_ERR_UNSUPPORTED);        // the named tile cannot run this problem (LDS-DMA tiles: tile_ok_for)
     p.uniform_tap = (d->n_seg == 1 && p.Cin % kTiles[sc.tile].bk == 0) ? 1 : 0;
     TSOD_REQUIRE(p.c2 == 0 || (p.uniform_tap && p.K1 % kTiles[sc.tile].bk == 0), TSOD_ERR_UNSUPPORTED);
     p.ksteps = (p.K + kTiles[sc.tile].bk - 1) / kTiles[sc.tile].bk;
@@ -1006,6 +1403,9 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
             case TSOD_TILE_128x64_S1: launch_tile<128, 64, 64, 32, 4, 1, 32, 1>(p, sc.grid, s); break;
             case TSOD_TILE_64x128_S1: launch_tile<64, 128, 32, 64, 4, 1, 32, 1>(p, sc.grid, s); break;
             case TSOD_TILE_128x128_S1: launch_tile<128, 128, 64, 64, 2, 1, 32, 1>(p, sc.grid, s); break;
+            case TSOD_TILE_D128x128: launch_dma_tile<128, 16, 1, 4>(p, sc.grid, s); break;
+            case TSOD_TILE_D64x128: launch_dma_tile<64, 32, 2, 3>(p, sc.grid, s); break;
+            case TSOD_TILE_D256x128: launch_dma_tile<256, 16, 1, 4>(p, sc.grid, s); break;
             default: launch_tile<64, 64, 32, 32, 2, 2, 32, 1>(p, sc.grid, s); break;      // TSOD_TILE_64x64 (two LDS stages)
         }
         return tsod_launch_status();
