@@ -402,7 +402,7 @@ def main(argv=None):
         tiles = {"serial": default_tiles, "in_flight": default_tiles}
         splits = [int(v) for v in args.autotune_splits.split(",")] if args.autotune_splits else None
         if splits is None and B >= 4:
-            splits = [1, -1, 2, 4]        # large M: tiles already outnumber the chip's slots many times; deep K-slicing never wins
+            splits = [1, -1, -2, 2, 4]    # large M: tiles already outnumber the chip's slots many times; deep K-slicing never wins
                                            # there and only lengthens the tuning pass (8 ranks tune at once in the N > 1 runs)
         tiles_loaded = bool(args.tiles_file and os.path.exists(args.tiles_file))
         if tiles_loaded:

@@ -73,7 +73,8 @@ enum { TSOD_TILE_AUTO = 0, TSOD_TILE_128x128 = 1, TSOD_TILE_128x64 = 2, TSOD_TIL
        TSOD_TILE_64x64_W1_S1 = 12, TSOD_TILE_128x64_W2_S1 = 13, TSOD_TILE_128x64_S1 = 14, TSOD_TILE_64x128_S1 = 15,
        TSOD_TILE_128x128_S1 = 16,
        /* bf16x3 only, fed by LDS-DMA (conv_dma_kernel): one channel segment, Cin a multiple of the K stage (16 / 32) */
-       TSOD_TILE_D128x128 = 17, TSOD_TILE_D64x128 = 18, TSOD_TILE_D256x128 = 19, TSOD_TILE_COUNT = 20 };
+       TSOD_TILE_D128x128 = 17, TSOD_TILE_D64x128 = 18, TSOD_TILE_D256x128 = 19,
+       TSOD_TILE_D64x128_S2 = 20 /* two ring stages: two workgroups per CU */, TSOD_TILE_COUNT = 21 };
 /* arithmetic of the contraction.  F32: v_mfma_f32_32x32x2_f32 (a k-ordered f32 fma chain).  BF16X3: every f32 operand cut
  * exactly into three bf16 pieces (hi + mid + lo == x), six piece products per k accumulated in f32 on
  * v_mfma_f32_32x32x16_bf16: f32-level accuracy (error ~1.3e-7 of sum|a*b|) at 0.375x the matrix-pipe time; storage,
@@ -105,7 +106,8 @@ typedef struct tsod_conv2d_desc {
     int32_t tile;          /* TSOD_TILE_*; AUTO = built-in heuristic */
     int32_t split_k;       /* 1 = whole tiles only; S > 1 = every tile cut into S K-slices; -1 = hybrid (full
                               chip-waves of whole tiles, left-over tiles K-sliced to fill the last wave);
-                              0 = built-in cost model chooses */
+                              -2 = balanced (TSOD_TILE_D* only): one workgroup per CU slot, each the same number of
+                              K-steps of the tile-major K-step sequence; 0 = built-in cost model chooses */
     int32_t precision;     /* TSOD_PREC_* (0 = F32) */
     /* optional SECOND source (tsod_conv2d_dual_f32; c2 = 0: none).  k in [KH*KW*Cin, KH*KW*Cin + c2) contracts channel
      * in2_off + (k - KH*KW*Cin) of pixel (oh*stride2, ow*stride2) of in2 [N][H2][W2][in2_pitch]: a strided 1x1 tap, i.e. a

@@ -7,7 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from two_stage_object_detection_amd import hip_ops  # noqa: E402
-from two_stage_object_detection_amd._ffi import BF16X3_TILE_IDS, TILE_IDS, TILE_NAMES  # noqa: E402
+from two_stage_object_detection_amd._ffi import BF16X3_TILE_IDS, DMA_TILE_IDS, TILE_IDS, TILE_NAMES  # noqa: E402
 
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
@@ -38,10 +38,12 @@ for name, H, W, Cin, Cout, k in shapes:
     for prec, tiles in ((0, TILE_IDS), (1, BF16X3_TILE_IDS)):
         out = []
         for tile in tiles:
-            for split in (1, -1, 2, 3, 4, 6, 8, 12):
+            for split in (1, -1, -2, 2, 3, 4, 6, 8, 12):
                 if split > 1 and ((Cin * k * k) // 32) // split < 2:
                     continue
                 if split > 1 and B * H * W > 20000:
+                    continue
+                if split == -2 and not (prec == 1 and tile in DMA_TILE_IDS):
                     continue
                 t = timeit(lambda: hip_ops.conv2d_nhwc(x, w, pad=k // 2, tile=tile, split_k=split, residual=res, act=1,
                                                        slope=0.25, precision=prec))

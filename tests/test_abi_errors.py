@@ -41,7 +41,7 @@ def test_conv_validation():
     assert L.tsod_conv2d_f32(byref(sliced), P, P, None, None, None, P, P, need - 1, None) == WORKSPACE
     tile, split = c_int32(-7), c_int32(-7)
     assert L.tsod_conv2d_resolve(byref(_desc()), byref(tile), byref(split)) == OK
-    assert tile.value in _ffi.TILE_IDS and -1 <= split.value <= 64 and split.value != 0
+    assert tile.value in _ffi.TILE_IDS and -2 <= split.value <= 64 and split.value != 0
     assert L.tsod_conv2d_resolve(byref(_desc(N=-1)), byref(tile), byref(split)) == INVALID
     assert L.tsod_conv2d_workspace_bytes(byref(_desc(N=-1))) == 0
 

@@ -106,7 +106,10 @@ def test_conv_bf16x3_matches_cpu(ops, dev, case, tile):
             ops.conv2d_nhwc(xn, wp, stride=stride, pad=pad, tile=tile, split_k=1, precision=1)
         return
     f32 = ops.nhwc_to_nchw(ops.conv2d_nhwc(xn, wp, stride=stride, pad=pad, tile=3, split_k=1)).cpu()
-    for split in [0, 1, -1] + [s for s in (2, 3, 6) if ksteps // s >= 2]:
+    if tile not in DMA_TILE_IDS and tile != 0:                # the balanced schedule exists for the LDS-DMA tiles only
+        with pytest.raises(TsodError, match="unsupported|UNSUPPORTED"):
+            ops.conv2d_nhwc(xn, wp, stride=stride, pad=pad, tile=tile, split_k=-2, precision=1)
+    for split in [0, 1, -1] + [s for s in (2, 3, 6) if ksteps // s >= 2] + ([-2] if tile in DMA_TILE_IDS else []):
         y = ops.conv2d_nhwc(xn, wp, stride=stride, pad=pad, tile=tile, split_k=split, precision=1)
         got = ops.nhwc_to_nchw(y).cpu()
         assert (got - ref).abs().max().item() <= tol, (case, tile, split)
@@ -524,8 +527,9 @@ def test_conv_dual_source_is_the_sum_of_two_convs(ops, dev, C1, C2, Cout, stride
     w = torch.cat([w3.flatten(1), wd.flatten(1)], dim=1).contiguous().to(dev)
     tol = 3e-6 * math.sqrt(C1 + C2) + 1e-5
     ran = 0
+    from two_stage_object_detection_amd._ffi import DMA_TILE_IDS
     for tile in [0] + list(BF16X3_TILE_IDS if prec else TILE_IDS):
-        for split in (0, 1, -1, 2, 3):
+        for split in (0, 1, -1, 2, 3) + ((-2,) if prec and tile in DMA_TILE_IDS else ()):
             out = ops.conv2d_nhwc(yn, w, segs=[(0, C1)], shift=shift.to(dev), act=ACT_PRELU, slope=0.25, tile=tile, split_k=split,
                                   precision=prec, x2=xn, stride2=stride2)
             ran += 1

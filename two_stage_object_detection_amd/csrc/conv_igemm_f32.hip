@@ -60,6 +60,7 @@ struct ConvParams {
     // schedule: workgroups [0, dp_tiles) each own one whole output tile; the remaining tiles are cut into
     // `split` K-slices, one workgroup per (tile, slice), partial sums reduced by conv_reduce_kernel
     int dp_tiles, split, ksteps_per_split;
+    int sk_q;                     // > 0: balanced schedule (conv_dma_kernel): K-steps per workgroup of the tile-major K-step sequence
     unsigned out_bytes, res_bytes;
     unsigned in_bytes, w_bytes;   // buffer-descriptor extents (hardware bounds check: out of range reads 0)
     int vec_epilogue;             // 1: channels/pitches/offsets are multiples of 4 -> dwordx4 epilogue
@@ -131,11 +132,28 @@ __device__ __forceinline__ int seg_channel(const ConvParams &p, int ci) {
 // acc[i][j][e]: column = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (m) of block (i, j) of wave (wm, wn).
 // z < 0: whole tile (BN / PReLU / ReLU6 / residual, then the store); z >= 0: K-slice z (slab + ticket + last-arriver combine).
 // `smem`: at least (THREADS / 64) * 32 * kPatchLD floats of LDS that no wave reads any more.
+// Which K-slice of its tile a workgroup holds and where every slice's slab is.  Uniform K-slices (desc.split_k = S / -1): tile
+// `ticket` of the K-sliced ones has p.split slices, slice s in slab ticket * split + s.  Balanced K ranges (split_k = -2, the
+// LDS-DMA kernel): workgroup w owns K-steps [w q, (w+1) q) of the launch's tile-major K-step sequence, so tile t is held by the
+// workgroups first .. first + count - 1, and workgroup w keeps the partial tile it STARTS inside in slab 2 w and the one it
+// ENDS inside (having started before that tile) in slab 2 w + 1 - at most those two are partial.
+struct SliceMap {
+    int z, count, ticket;         // this workgroup's slice (-1: it holds the whole tile), slices of the tile, ticket index
+    int first;                    // balanced ranges: first workgroup of the tile (-1: uniform K-slices)
+    long q, tile_k0;              // balanced ranges: K-steps per workgroup, first K-step of the tile in the launch's sequence
+    __device__ __forceinline__ unsigned slab(int s) const {
+        if (first < 0) return (unsigned)(ticket * count + s);
+        const long w = first + s;
+        return (unsigned)(2 * w + (w * q < tile_k0 ? 1 : 0));
+    }
+};
+
 template <int BM, int BN, int WM, int WN, int THREADS>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[WM / 32][WN / 32], float *smem, int tid, int wm, int wn,
-                                              int m0, int n0, int z, int tile_id) {
+                                              int m0, int n0, const SliceMap sm) {
     constexpr int TM = WM / 32, TN = WN / 32;
     const int lane = tid & 63, wave = tid >> 6;
+    const int z = sm.z;
     // ---- epilogue.  acc[i][j][e]: column = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (m).
     // All global accesses go through buffer descriptors: rows / columns outside the problem get the
     // out-of-range offset, so there is no per-element branch (loads return 0, stores are dropped), and the
@@ -151,9 +169,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
         // to the ticket at agent scope, and the reducer reads EVERY slab byte with sc1 loads (never through a stale L1/L2 line).
         constexpr int AUX_SC1 = 16;
         const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc((void *)p.partial, (short)0, (int)p.part_bytes, 0x00020000);
-        const int rem = tile_id - p.dp_tiles;
-        const unsigned slab0 = (unsigned)rem * (unsigned)p.split * (unsigned)(BM * BN * 4);   // byte offset of slice 0's slab
-        const unsigned my_slab = slab0 + (unsigned)z * (unsigned)(BM * BN * 4);
+        const int rem = sm.ticket;
+        const unsigned my_slab = sm.slab(z) * (unsigned)(BM * BN * 4);                       // byte offset of this slice's slab
         {
             float *patch = smem + wave * (32 * kPatchLD);
             const int pr = lane >> 3, pc = (lane & 7) * 4;
@@ -181,7 +198,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
         int *s_flag = reinterpret_cast<int *>(smem);                       // the one LDS array (patches are idle past the barrier)
         if (tid == 0) {
             const int old = __hip_atomic_fetch_add(p.tickets + rem, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = old == p.split - 1;
+            const int last = old == sm.count - 1;
             if (last) __hip_atomic_store(p.tickets + rem, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every slice has arrived
             s_flag[0] = last;
         }
@@ -191,43 +208,63 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
         const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, (short)0, (int)p.out_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), (short)0,
                                                                                (int)(p.res ? p.res_bytes : 0u), 0x00020000);
-        constexpr int QPR = BN / 4, QUADS = BM * BN / 4;
-        for (int q = tid; q < QUADS; q += THREADS) {
-            const unsigned qoff = slab0 + (unsigned)q * 16u;
-            float4 v = buffer_load4_aux<AUX_SC1>(rs_part, qoff);
-            int sl = 1;
-            for (; sl + 4 <= p.split; sl += 4) {                           // 4 slab loads in flight, added in slice order
-                float4 t4[4];
+        // The combine is a latency chain (every slab byte comes from beyond this XCD's L2), so a thread keeps ALL the loads of
+        // a slice in flight at once - QB quads (16 bytes each) per pass - and pays one round trip per slice and pass, not one
+        // per quad; slices are still added in slice order (bit-reproducible).
+        constexpr int QPR = BN / 4, QUADS = BM * BN / 4, QPT = QUADS / THREADS, QB = QPT < 8 ? QPT : 8;
+        static_assert(QUADS % THREADS == 0 && QPT % QB == 0, "quads per thread");
+        const unsigned slab_bytes = (unsigned)(BM * BN * 4);
+#pragma unroll 1
+        for (int pass = 0; pass < QPT / QB; ++pass) {
+            float4 v[QB], rs4[QB];
+            unsigned qoff[QB];
+            int mq[QB], nq[QB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) t4[u] = buffer_load4_aux<AUX_SC1>(rs_part, qoff + (unsigned)(sl + u) * (unsigned)(BM * BN * 4));
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { v.x += t4[u].x; v.y += t4[u].y; v.z += t4[u].z; v.w += t4[u].w; }
+            for (int u = 0; u < QB; ++u) {
+                const int q = tid + THREADS * (pass * QB + u);
+                qoff[u] = (unsigned)q * 16u;
+                mq[u] = m0 + q / QPR;
+                nq[u] = n0 + (q % QPR) * 4;
+                v[u] = buffer_load4_aux<AUX_SC1>(rs_part, sm.slab(0) * slab_bytes + qoff[u]);
             }
-            for (; sl < p.split; ++sl) {
-                const float4 t1 = buffer_load4_aux<AUX_SC1>(rs_part, qoff + (unsigned)sl * (unsigned)(BM * BN * 4));
-                v.x += t1.x; v.y += t1.y; v.z += t1.z; v.w += t1.w;
-            }
-            const int m = m0 + q / QPR, n = n0 + (q % QPR) * 4;
-            if (m >= p.M || n >= p.Cout) continue;
-            float vv[4] = {v.x, v.y, v.z, v.w};
-            if (p.vec_epilogue) {                                          // Cout % 4 == 0: all four channels exist
-                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + n);
-                if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + n);
-                const float4 rs4 = buffer_load4(rs_r, p.res ? ((unsigned)m * (unsigned)p.res_pitch + (unsigned)(p.res_off + n)) * 4u : kOOB);
-                u32x4 o;
-                o.x = __float_as_uint(apply_act(vv[0] * sc.x + sh.x + rs4.x, p.neg_slope, p.act_hi));
-                o.y = __float_as_uint(apply_act(vv[1] * sc.y + sh.y + rs4.y, p.neg_slope, p.act_hi));
-                o.z = __float_as_uint(apply_act(vv[2] * sc.z + sh.z + rs4.z, p.neg_slope, p.act_hi));
-                o.w = __float_as_uint(apply_act(vv[3] * sc.w + sh.w + rs4.w, p.neg_slope, p.act_hi));
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u, 0, 0);
-            } else {
+            if (p.vec_epilogue) {                                          // the residual rides along with the first slice
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (n + c >= p.Cout) continue;
-                    float o = vv[c] * (p.scale ? p.scale[n + c] : 1.f) + (p.shift ? p.shift[n + c] : 0.f);
-                    if (p.res) o += p.res[(long)m * p.res_pitch + p.res_off + n + c];
-                    p.out[(long)m * p.out_pitch + p.out_off + n + c] = apply_act(o, p.neg_slope, p.act_hi);
+                for (int u = 0; u < QB; ++u) {
+                    const bool ok = mq[u] < p.M && nq[u] < p.Cout && p.res != nullptr;
+                    rs4[u] = buffer_load4(rs_r, ok ? ((unsigned)mq[u] * (unsigned)p.res_pitch + (unsigned)(p.res_off + nq[u])) * 4u : kOOB);
+                }
+            }
+            for (int sl = 1; sl < sm.count; ++sl) {
+                float4 t[QB];
+                const unsigned so = sm.slab(sl) * slab_bytes;
+#pragma unroll
+                for (int u = 0; u < QB; ++u) t[u] = buffer_load4_aux<AUX_SC1>(rs_part, so + qoff[u]);
+#pragma unroll
+                for (int u = 0; u < QB; ++u) { v[u].x += t[u].x; v[u].y += t[u].y; v[u].z += t[u].z; v[u].w += t[u].w; }
+            }
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+                const int m = mq[u], n = nq[u];
+                if (m >= p.M || n >= p.Cout) continue;
+                float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                if (p.vec_epilogue) {                                      // Cout % 4 == 0: all four channels exist
+                    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + n);
+                    if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + n);
+                    u32x4 o;
+                    o.x = __float_as_uint(apply_act(vv[0] * sc.x + sh.x + rs4[u].x, p.neg_slope, p.act_hi));
+                    o.y = __float_as_uint(apply_act(vv[1] * sc.y + sh.y + rs4[u].y, p.neg_slope, p.act_hi));
+                    o.z = __float_as_uint(apply_act(vv[2] * sc.z + sh.z + rs4[u].z, p.neg_slope, p.act_hi));
+                    o.w = __float_as_uint(apply_act(vv[3] * sc.w + sh.w + rs4[u].w, p.neg_slope, p.act_hi));
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u, 0, 0);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (n + c >= p.Cout) continue;
+                        float o = vv[c] * (p.scale ? p.scale[n + c] : 1.f) + (p.shift ? p.shift[n + c] : 0.f);
+                        if (p.res) o += p.res[(long)m * p.res_pitch + p.res_off + n + c];
+                        p.out[(long)m * p.out_pitch + p.out_off + n + c] = apply_act(o, p.neg_slope, p.act_hi);
+                    }
                 }
             }
         }
@@ -703,7 +740,8 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
         g_clock_buf[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - diag_r0;
     }
 #endif
-    conv_epilogue<BM, BN, WM, WN, THREADS>(p, acc, smem, tid, wm, wn, m0, n0, z, tile_id);
+    const SliceMap sm = {z, p.split, tile_id - p.dp_tiles, -1, 0, 0};
+    conv_epilogue<BM, BN, WM, WN, THREADS>(p, acc, smem, tid, wm, wn, m0, n0, sm);
 }
 
 // =====================================================================================================================
@@ -800,22 +838,47 @@ conv_dma_kernel(const ConvParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WAVES_M, wk = wave / WAVES_M;
-    int tile_id, z;
-    if ((int)blockIdx.x < p.dp_tiles) {                               // same workgroup -> work map as conv_igemm_kernel
-        const int nwg = p.dp_tiles;
-        const int q = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
-        tile_id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (blockIdx.x >> 3);
-        z = -1;
+    // ---- work of this workgroup: ONE (tile, K range) under the uniform schedules (the map of conv_igemm_kernel), or the K-steps
+    // [w q, (w+1) q) of the launch's tile-major K-step sequence under the balanced schedule (p.sk_q > 0): a run of up to two
+    // partial tiles with whole tiles between them, every workgroup the same number of K-steps whatever the tile count
+    const bool balanced = p.sk_q > 0;
+    long g = 0, g_end = 1;
+    if (balanced) {
+        g = (long)blockIdx.x * p.sk_q;
+        g_end = min(g + (long)p.sk_q, (long)p.tiles_m * p.tiles_n * p.ksteps);
+    }
+  for (; g < g_end;) {
+    int tile_id, kt_begin, kt_end;
+    SliceMap sm;
+    if (balanced) {
+        tile_id = (int)(g / p.ksteps);
+        const long tile_k0 = (long)tile_id * p.ksteps;
+        kt_begin = (int)(g - tile_k0);
+        kt_end = (int)min((long)p.ksteps, kt_begin + (g_end - g));
+        const int first = (int)(tile_k0 / p.sk_q), last = (int)((tile_k0 + p.ksteps - 1) / p.sk_q);
+        sm = {first == last ? -1 : (int)blockIdx.x - first, last - first + 1, tile_id, first, (long)p.sk_q, tile_k0};
+        g += kt_end - kt_begin;
     } else {
-        const int r = blockIdx.x - p.dp_tiles;
-        tile_id = p.dp_tiles + r / p.split;
-        z = r % p.split;
+        int z;
+        if ((int)blockIdx.x < p.dp_tiles) {
+            const int nwg = p.dp_tiles;
+            const int q = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+            tile_id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (blockIdx.x >> 3);
+            z = -1;
+        } else {
+            const int r = blockIdx.x - p.dp_tiles;
+            tile_id = p.dp_tiles + r / p.split;
+            z = r % p.split;
+        }
+        kt_begin = z < 0 ? 0 : z * p.ksteps_per_split;
+        kt_end = z < 0 ? p.ksteps : min(p.ksteps, kt_begin + p.ksteps_per_split);
+        sm = {z, p.split, tile_id - p.dp_tiles, -1, 0, 0};
+        g = g_end;
     }
     const int tn_i = tile_id % p.tiles_n, tm_i = tile_id / p.tiles_n;
     const int m0 = tm_i * BM, n0 = tn_i * BN;
-    const int kt_begin = z < 0 ? 0 : z * p.ksteps_per_split;
-    const int kt_end = z < 0 ? p.ksteps : min(p.ksteps, kt_begin + p.ksteps_per_split);
     const int nk = kt_end - kt_begin;
+    __syncthreads();                                             // (a previous segment's epilogue is done with the LDS)
 
     const v4i32 rs_in = dma_rsrc(p.in, p.in_bytes), rs_w = dma_rsrc(p.w, p.w_bytes);
     const v4i32 rs_in2 = dma_rsrc(p.in2 ? p.in2 : p.in, p.in2 ? p.in2_bytes : 0u);
@@ -1069,10 +1132,11 @@ conv_dma_kernel(const ConvParams p) {
                 for (int e = 0; e < 16; ++e) acc2[0][b][e] = smem[((partner * 2 + b) * 16 + e) * 64 + lane] + acc[0][2 + b][e];
         }
         __syncthreads();
-        conv_epilogue<BM, BN, 32, 64, THREADS>(p, acc2, smem, tid, wm, wk, m0, n0, z, tile_id);
+        conv_epilogue<BM, BN, 32, 64, THREADS>(p, acc2, smem, tid, wm, wk, m0, n0, sm);
     } else {
-        conv_epilogue<BM, BN, 32, 128, THREADS>(p, acc, smem, tid, wm, 0, m0, n0, z, tile_id);
+        conv_epilogue<BM, BN, 32, 128, THREADS>(p, acc, smem, tid, wm, 0, m0, n0, sm);
     }
+  }
 }
 
 // torch [Cout][Cin_src][KH][KW_src] -> [Cout][KH][KW][Cin], zero-filling the added channels / taps
@@ -1126,7 +1190,8 @@ const TileInfo kTiles[TSOD_TILE_COUNT] = {
     {64, 64, 256, 6, 1.20f, 32, 1, 1},  {128, 64, 512, 3, 1.10f, 32, 1, 1},  {64, 64, 256, 4, 1.10f, 64, 1, 1},  {128, 64, 512, 2, 1.05f, 64, 1, 0},
     {64, 64, 64, 8, 1.40f, 32, 1, 0},   {128, 64, 128, 4, 1.35f, 32, 1, 0}, {128, 64, 256, 4, 1.12f, 32, 1, 1}, {64, 128, 256, 4, 1.12f, 32, 1, 1},
     {128, 128, 256, 2, 1.02f, 32, 1, 1},
-    {128, 128, 256, 2, 0.80f, 16, 4, 1, 1}, {64, 128, 256, 1, 0.95f, 32, 3, 1, 1}, {256, 128, 512, 1, 0.72f, 16, 4, 1, 1}};
+    {128, 128, 256, 2, 0.80f, 16, 4, 1, 1}, {64, 128, 256, 1, 0.95f, 32, 3, 1, 1}, {256, 128, 512, 1, 0.72f, 16, 4, 1, 1},
+    {64, 128, 256, 2, 0.98f, 32, 2, 1, 1}};
 // bf16x3 = 1: the tile also exists as a bf16x3 variant (three bf16 planes per operand fit the 64 KB of static LDS)
 
 // workgroups per CU: the f32 figure (VGPR / LDS bound), for bf16x3 additionally capped by its larger LDS footprint
@@ -1154,7 +1219,7 @@ int validate(const tsod_conv2d_desc *d) {
     TSOD_REQUIRE((d->OH - 1) * d->stride - d->pad_h < d->H && (d->OW - 1) * d->stride - d->pad_w < d->W,
                  TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->act >= TSOD_ACT_NONE && d->act <= TSOD_ACT_RELU, TSOD_ERR_INVALID_ARG);
-    TSOD_REQUIRE(d->tile >= 0 && d->tile < TSOD_TILE_COUNT && d->split_k >= -1 && d->split_k <= 64, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(d->tile >= 0 && d->tile < TSOD_TILE_COUNT && d->split_k >= -2 && d->split_k <= 64, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->precision == TSOD_PREC_BF16X3, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->tile == TSOD_TILE_AUTO || kTiles[d->tile].bf16x3, TSOD_ERR_UNSUPPORTED);
     TSOD_REQUIRE(d->precision == TSOD_PREC_BF16X3 || d->tile == TSOD_TILE_AUTO || !kTiles[d->tile].dma, TSOD_ERR_UNSUPPORTED);
@@ -1209,13 +1274,16 @@ constexpr size_t kTicketBytes = 256 * 1024;   // tickets for up to 65536 K-slice
 
 struct Sched {
     int tile, bm, bn, tiles_m, tiles_n, tiles, dp_tiles, rem_tiles, split, ksteps_per_split, grid;
+    int sk_q;                     // balanced schedule: K-steps per workgroup (0: a uniform schedule)
     size_t ws_bytes, ticket_bytes;
     double cost;
 };
 
 // desc.split_k:  1 = every tile whole (no K split);  S > 1 = every tile cut into S K-slices;
 //               -1 = hybrid: as many full chip-waves of whole tiles as fit, the left-over tiles cut into
-//                    K-slices so that the last wave also fills the chip;  0 = let the cost model choose.
+//                    K-slices so that the last wave also fills the chip;  0 = let the cost model choose;
+//               -2 = balanced (LDS-DMA tiles only): one workgroup per CU slot, each the same number of K-steps of the
+//                    tile-major K-step sequence (a tile held by several workgroups is combined like K-slices).
 Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
     Sched s;
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
@@ -1226,6 +1294,26 @@ Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
     s.tiles_m = (int)tsod_cdiv(M, s.bm); s.tiles_n = (int)tsod_cdiv(d->Cout, s.bn);
     s.tiles = s.tiles_m * s.tiles_n;
     const int slots = cu_count() * residency(tile, d->precision);
+    s.sk_q = 0;
+    if (mode == -2) {
+        const int64_t total = (int64_t)s.tiles * ksteps;
+        int64_t q = tsod_cdiv(total, slots);
+        if (q < 4) q = 4;                                         // a workgroup's prologue / epilogue need some K loop to pay for
+        const int64_t grid = tsod_cdiv(total, q);
+        if (kTiles[tile].dma && q < INT_MAX && (size_t)s.tiles * sizeof(int) <= kTicketBytes) {
+            s.sk_q = (int)q; s.grid = (int)grid;
+            s.split = 1; s.ksteps_per_split = ksteps; s.dp_tiles = 0; s.rem_tiles = s.tiles;
+            s.ticket_bytes = kTicketBytes;
+            s.ws_bytes = s.ticket_bytes + (size_t)grid * 2 * s.bm * s.bn * sizeof(float);
+            const double step = (double)s.bm * s.bn / 4.0 * kTiles[tile].cost * (bk / 32.0) * 0.55;
+            const double fixed = 3000.0 + (double)s.bm * s.bn / 8.0;
+            s.cost = (double)q * step + fixed * (1.0 + (double)q / ksteps) + 2500.0 + 2.0 * s.bm * s.bn * 4.0 / 60.0;
+            return s;
+        }
+        s.cost = 1e300;                                           // not a tile that knows this schedule
+        s.split = 1; s.ksteps_per_split = ksteps; s.dp_tiles = s.tiles; s.rem_tiles = 0; s.grid = s.tiles; s.ws_bytes = 0; s.ticket_bytes = 0;
+        return s;
+    }
     int split = 1, dp = s.tiles;
     if (mode > 1) {
         split = mode < ksteps ? mode : ksteps;
@@ -1255,7 +1343,7 @@ Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
 
     // cost, in cycles of the most loaded CU: co-resident workgroups share the CU's matrix pipes, so a wave of
     // workgroups costs (workgroups per CU) x (K-steps x BM*BN/4 MFMA cycles + fixed prologue/epilogue)
-    const double step = (double)s.bm * s.bn / 4.0 * kTiles[tile].cost * (bk / 32) * (d->precision ? 0.55 : 1.0);
+    const double step = (double)s.bm * s.bn / 4.0 * kTiles[tile].cost * (bk / 32.0) * (d->precision ? 0.55 : 1.0);
     const double fixed = 3000.0 + (double)s.bm * s.bn / 8.0;
     const int cus = cu_count();
     double c = (double)tsod_cdiv(dp, cus) * (ksteps * step + fixed);
@@ -1281,8 +1369,9 @@ Sched resolve(const tsod_conv2d_desc *d) {
         }
         const int K = desc_k(d);
         const int ksteps = (K + kTiles[t].bk - 1) / kTiles[t].bk;
-        for (int mode : {1, -1, 2, 4, 8, 16}) {
+        for (int mode : {1, -1, 2, 4, 8, 16, -2}) {
             if (mode > 1 && ksteps / mode < 2) continue;
+            if (mode == -2 && !kTiles[t].dma) continue;
             const Sched s = make_sched(d, t, mode);
             if (s.cost < best.cost) best = s;
         }
@@ -1309,7 +1398,7 @@ extern "C" int tsod_conv2d_resolve(const tsod_conv2d_desc *d, int32_t *tile, int
     const Sched s = resolve(d);
     TSOD_REQUIRE(s.cost < 1e299, TSOD_ERR_UNSUPPORTED);
     *tile = s.tile;
-    *split_k = s.rem_tiles == 0 ? 1 : (s.dp_tiles == 0 ? s.split : -1);
+    *split_k = s.sk_q > 0 ? -2 : (s.rem_tiles == 0 ? 1 : (s.dp_tiles == 0 ? s.split : -1));
     return TSOD_OK;
 }
 
@@ -1387,7 +1476,7 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
     TSOD_REQUIRE(p.c2 == 0 || (p.uniform_tap && p.K1 % kTiles[sc.tile].bk == 0), TSOD_ERR_UNSUPPORTED);
     p.ksteps = (p.K + kTiles[sc.tile].bk - 1) / kTiles[sc.tile].bk;
     p.tiles_m = sc.tiles_m; p.tiles_n = sc.tiles_n;
-    p.dp_tiles = sc.dp_tiles; p.split = sc.split; p.ksteps_per_split = sc.ksteps_per_split;
+    p.dp_tiles = sc.dp_tiles; p.split = sc.split; p.ksteps_per_split = sc.ksteps_per_split; p.sk_q = sc.sk_q;
     if (sc.rem_tiles > 0)
         TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= sc.ws_bytes && tsod_aligned16(workspace), TSOD_ERR_WORKSPACE);
     p.tickets = static_cast<int *>(workspace);
@@ -1406,6 +1495,7 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
             case TSOD_TILE_D128x128: launch_dma_tile<128, 16, 1, 4>(p, sc.grid, s); break;
             case TSOD_TILE_D64x128: launch_dma_tile<64, 32, 2, 3>(p, sc.grid, s); break;
             case TSOD_TILE_D256x128: launch_dma_tile<256, 16, 1, 4>(p, sc.grid, s); break;
+            case TSOD_TILE_D64x128_S2: launch_dma_tile<64, 32, 2, 2>(p, sc.grid, s); break;
             default: launch_tile<64, 64, 32, 32, 2, 2, 32, 1>(p, sc.grid, s); break;      // TSOD_TILE_64x64 (two LDS stages)
         }
         return tsod_launch_status();

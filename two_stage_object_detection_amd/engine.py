@@ -284,7 +284,7 @@ class Plan:
             cands = []
             for prec in (precisions if precisions is not None else (int(d.precision),)):
                 for tile in (_ffi.BF16X3_TILE_IDS if prec == _ffi.PREC_BF16X3 else _ffi.TILE_IDS):
-                    for split in (splits or (1, -1, 2, 3, 4, 6, 8, 12, 16, 24, 32)):
+                    for split in (splits or (1, -1, -2, 2, 3, 4, 6, 8, 12, 16, 24, 32)):
                         if split > 1 and ksteps // split < 2:
                             continue
                         st.choose(tile, split, prec)

@@ -193,7 +193,7 @@ def tune_conv(x: torch.Tensor, w_packed: torch.Tensor, reps: int = 5, precisions
     best = None
     for prec in precisions:
         for tile in (_ffi.BF16X3_TILE_IDS if prec == _ffi.PREC_BF16X3 else _ffi.TILE_IDS):
-            for split in (1, -1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+            for split in (1, -1, -2, 2, 3, 4, 6, 8, 12, 16, 24, 32):
                 if split > 1 and ksteps // split < 2:
                     continue
                 try:
