@@ -225,6 +225,7 @@ def pmc_traffic(args, tiles, n_launches):
                 return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
             rows = [(int(q["Dispatch_Id"]), float(q["Counter_Value"])) for q in csv.DictReader(open(files[0]))
                     if q["Counter_Name"] == counter and ("conv_igemm_kernel" in q["Kernel_Name"]
+                                                         or "conv_dma_kernel" in q["Kernel_Name"]
                                                          or "conv_reduce_kernel" in q["Kernel_Name"])]
             rows.sort()
             if not rows or len(rows) % 2:
@@ -545,7 +546,7 @@ def main(argv=None):
                                          + ("" if traffic_note is None else f" [{traffic_note}]"),
                          "algorithmic_bytes_per_launch": round(algo_bytes / len(conv_ms)),
                          "traffic_over_algorithmic": None if traffic is None else round(traffic * len(conv_ms) / algo_bytes, 3),
-                         "kernel": f"conv_igemm_kernel (implicit GEMM, f32 MFMA / bf16x3 MFMA per layer), {len(conv_ms)} launches per forward",
+                         "kernel": f"conv_igemm_kernel / conv_dma_kernel (implicit GEMM; per layer f32 MFMA, bf16x3 MFMA register-staged, or bf16x3 MFMA fed by LDS-DMA), {len(conv_ms)} launches per forward",
                          "schedule": "serial", "flops_per_forward": conv_flops,
                          "kernel_ms_per_forward": round(conv_total_ms, 4),
                          "serial_ms_per_step": round(serial["ms_per_step"], 4),

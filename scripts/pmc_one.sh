@@ -20,7 +20,7 @@ for d in sorted(glob.glob("$R/gpurun_out/pmc_${tag}_*")):
     dur = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt))}
     acc = collections.defaultdict(list); us = []
     for r in csv.DictReader(open(f[0])):
-        if "conv_igemm" in r["Kernel_Name"]:
+        if "conv_igemm" in r["Kernel_Name"] or "conv_dma" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"])); us.append(dur[r["Dispatch_Id"]])
     if not us: continue
     t = sum(us) / len(us)

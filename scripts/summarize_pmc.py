@@ -16,6 +16,8 @@ def short(n):
 
 def arith(k):
     """conv_igemm_kernel<BM, BN, WM, WN, MINW, NBUF, BK, PREC>: PREC 1 = bf16x3"""
+    if 'conv_dma' in k:
+        return 'bf16x3 (LDS-DMA)'
     m = re.search(r'<([^>]*)>', k)
     return 'bf16x3' if m and m.group(1).replace(' ', '').split(',')[-1] == '1' and len(m.group(1).split(',')) == 8 else 'f32'
 
@@ -36,8 +38,8 @@ print(f"# {label} - PMC counters, `bench.py --no-graph --in-flight 1` (B=1, 3x80
 print("Per dispatch, averaged over the second half of each kernel's dispatches (the timed steps; the first half contains plan")
 print("building and autotune-free warm-up).  `FETCH_SIZE` / `WRITE_SIZE` are KiB; on gfx950 `FETCH_SIZE` under-reports wide")
 print("coalesced reads by 2x (MI355X_MICROARCH.md, HBM section), so HBM read bytes = 2 x FETCH_SIZE.  Commands: profiles/README.md.\n")
-g = [c.get('GRBM_GUI_ACTIVE') for k in fe if 'conv_igemm' in k for _, c in fe[k].items() if c.get('GRBM_GUI_ACTIVE')]
-d = [dfe[i] for k in fe if 'conv_igemm' in k for i, c in fe[k].items() if c.get('GRBM_GUI_ACTIVE')]
+g = [c.get('GRBM_GUI_ACTIVE') for k in fe if ('conv_igemm' in k or 'conv_dma' in k) for _, c in fe[k].items() if c.get('GRBM_GUI_ACTIVE')]
+d = [dfe[i] for k in fe if ('conv_igemm' in k or 'conv_dma' in k) for i, c in fe[k].items() if c.get('GRBM_GUI_ACTIVE')]
 clock_meas = sum(g) / 8 / (sum(d) * 1e-6) if d else 2.4e9
 clock = min(clock_meas, 2.4e9)
 print("## Matrix-core utilisation of the conv GEMMs (pass 1: SQ counters)\n")
@@ -47,7 +49,7 @@ print("| kernel | arithmetic | dispatches | avg us | MFMA busy | SQ_WAIT_INST_AN
 print("|---|---|---:|---:|---:|---:|---:|")
 tot = collections.defaultdict(lambda: [0.0, 0.0])
 for k in sorted(sq):
-    if 'conv_igemm' not in k:
+    if 'conv_igemm' not in k and 'conv_dma' not in k:
         continue
     ds = list(sq[k].items()); ds = ds[len(ds) // 2:]
     n = len(ds)
@@ -84,7 +86,7 @@ def last_forward(per):
     start = max(int(i) for k in per if 'nchw_to_nhwc' in k for i in per[k])
     out = collections.defaultdict(lambda: [0, 0.0])
     for k in per:
-        fam = 'conv_igemm_kernel' if 'conv_igemm' in k else k
+        fam = 'conv_igemm_kernel' if ('conv_igemm' in k or 'conv_dma' in k) else k
         for i, c in per[k].items():
             if int(i) >= start:
                 out[fam][0] += 1

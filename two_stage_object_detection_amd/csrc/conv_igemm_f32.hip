@@ -816,7 +816,7 @@ __device__ __forceinline__ void gap_read(f32x16 &c, const bf16x8 &a, const bf16x
 
 constexpr int dma_stage_bytes(int bm, int bk) { return bm * bk * 4 + 3 * 128 * bk * 2; }
 
-template <int BM, int BK, int WAVES_K, int S>
+template <int BM, int BK, int WAVES_K, int S, bool BALANCED>
 __global__ void __launch_bounds__((BM / 32) * WAVES_K * 64, (2 * S * dma_stage_bytes(BM, BK) <= 160 * 1024) ? 2 : 1)
 conv_dma_kernel(const ConvParams p) {
     constexpr int BN = 128, TN = 4, WAVES_M = BM / 32, WAVES = WAVES_M * WAVES_K, THREADS = WAVES * 64;
@@ -841,7 +841,9 @@ conv_dma_kernel(const ConvParams p) {
     // ---- work of this workgroup: ONE (tile, K range) under the uniform schedules (the map of conv_igemm_kernel), or the K-steps
     // [w q, (w+1) q) of the launch's tile-major K-step sequence under the balanced schedule (p.sk_q > 0): a run of up to two
     // partial tiles with whole tiles between them, every workgroup the same number of K-steps whatever the tile count
-    const bool balanced = p.sk_q > 0;
+    // (BALANCED is a template argument: the loop over segments keeps enough scalar state alive to push the K loop's own
+    //  scalars out of the SGPR file - the uniform-schedule instantiation has no such loop)
+    constexpr bool balanced = BALANCED;
     long g = 0, g_end = 1;
     if (balanced) {
         g = (long)blockIdx.x * p.sk_q;
@@ -1381,7 +1383,10 @@ Sched resolve(const tsod_conv2d_desc *d) {
 
 template <int BM, int BK, int WAVES_K, int S>
 void launch_dma_tile(const ConvParams &p, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S>), dim3(grid), dim3((BM / 32) * WAVES_K * 64), 0, s, p);
+    if (p.sk_q > 0)
+        hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S, true>), dim3(grid), dim3((BM / 32) * WAVES_K * 64), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S, false>), dim3(grid), dim3((BM / 32) * WAVES_K * 64), 0, s, p);
 }
 
 template <int BM, int BN, int WM, int WN, int MW, int NBUF = 2, int BK = 32, int PREC = 0>
