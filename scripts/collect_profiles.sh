@@ -19,8 +19,8 @@ cd $R
 python3 scripts/summarize_trace.py $(ls $O/trace_serial/*/*kernel_trace.csv) 20 > $O/serial_kernel_trace_summary.md
 python3 scripts/summarize_trace.py $(ls $O/trace_default/*/*kernel_trace.csv) 20 > $O/default_kernel_trace_summary.md
 python3 scripts/summarize_pmc.py "Round ${tag#r}" $O/pmc_sq $O/pmc_fetch $O/pmc_write > $O/pmc_summary.md
-tail -1 $O/trace_serial.log > $O/bench_serial_under_rocprof.json
-tail -1 $O/trace_default.log > $O/bench_default_under_rocprof.json
+grep "^{" $O/trace_serial.log | tail -1 > $O/bench_serial_under_rocprof.json
+grep "^{" $O/trace_default.log | tail -1 > $O/bench_default_under_rocprof.json
 cp $(ls $O/trace_serial/*/*kernel_stats.csv) $O/serial_rocprofv3_kernel_stats.csv
 cp $(ls $O/trace_default/*/*kernel_stats.csv) $O/default_rocprofv3_kernel_stats.csv
 rm -rf $O/trace_serial $O/trace_default $O/pmc_sq $O/pmc_fetch $O/pmc_write

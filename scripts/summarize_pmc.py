@@ -86,7 +86,7 @@ def last_forward(per):
     start = max(int(i) for k in per if 'nchw_to_nhwc' in k for i in per[k])
     out = collections.defaultdict(lambda: [0, 0.0])
     for k in per:
-        fam = 'conv_igemm_kernel' if ('conv_igemm' in k or 'conv_dma' in k) else k
+        fam = 'conv_igemm_kernel + conv_dma_kernel' if ('conv_igemm' in k or 'conv_dma' in k) else k
         for i, c in per[k].items():
             if int(i) >= start:
                 out[fam][0] += 1
@@ -98,7 +98,7 @@ lf, lw = last_forward(fe), last_forward(wr)
 print("\n## HBM traffic of the conv GEMMs in one forward (last forward of passes 2 and 3)\n")
 print("| kernel family | dispatches | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM MB = (2*FETCH+WRITE)*1024/1e6 |")
 print("|---|---:|---:|---:|---:|")
-fam = 'conv_igemm_kernel'
+fam = 'conv_igemm_kernel + conv_dma_kernel'
 if fam in lf:
     mb = (2 * lf[fam][1] + lw[fam][1]) * 1024 / 1e6
     print(f"| `{fam}` | {lf[fam][0]} | {lf[fam][1]:.0f} | {lw[fam][1]:.0f} | {mb:.1f} |")
