@@ -769,9 +769,20 @@ __device__ __forceinline__ v4i32 dma_rsrc(const void *ptr, unsigned bytes) {
     return r;
 }
 // one wave-instruction: 64 lanes x 16 bytes from per-lane source offsets to LDS [lds_dst, lds_dst + 1024)
+#ifndef TSOD_DMA_POLICY_A
+#define TSOD_DMA_POLICY_A ""       /* cache policy suffix of the activation / weight DMAs (experiments: " nt", " sc0", " sc1") */
+#endif
+#ifndef TSOD_DMA_POLICY_B
+#define TSOD_DMA_POLICY_B ""
+#endif
+template <int WEIGHTS = 0>
 __device__ __forceinline__ void dma16(unsigned voff, v4i32 rsrc, unsigned soff, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+    if (WEIGHTS)
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen" TSOD_DMA_POLICY_B " lds"
+                     :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen" TSOD_DMA_POLICY_A " lds"
+                     :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); }
@@ -979,7 +990,7 @@ conv_dma_kernel(const ConvParams p) {
             // (a padding piece has the out-of-range source everywhere; its destination is the scratch KiB behind the ring, which
             //  the slot offset must not move: ldst - lds0 == S * STAGE marks it)
             const unsigned dst = (B_PAD && ldst[i] - lds0 == (unsigned)(S * STAGE)) ? ldst[i] : ldst[i] + slot * STAGE;
-            dma16(b_voff[i - PA_W], u_rs_w, u_woff, dst);
+            dma16<1>(b_voff[i - PA_W], u_rs_w, u_woff, dst);
         }
     };
 
