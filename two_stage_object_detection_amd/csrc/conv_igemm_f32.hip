@@ -1116,6 +1116,10 @@ conv_dma_kernel(const ConvParams p) {
 #undef TSOD_DMA
     __syncthreads();                                             // no wave reads the ring any more: the epilogue may use it
     float *smem = reinterpret_cast<float *>(lds);
+    // The epilogue reads its parameters from the kernel-argument segment (the struct is the only argument) instead of from
+    // `p`: values that only the epilogue needs then do not occupy scalar registers across the K loop (under the balanced
+    // schedule's segment loop they pushed the loop's own scalars out into v_readlane / v_writelane).
+    const ConvParams &pe = *(const ConvParams *)__builtin_amdgcn_kernarg_segment_ptr();
     if constexpr (WAVES_K == 2) {
         // the two K halves of a 32 x 128 stripe sit in waves (wm, 0) and (wm, 1): each keeps the 64 columns [64 wk, 64 wk + 64),
         // hands the other 64 over through LDS ([wave][block][e][lane], lane-contiguous) and adds what its partner handed over
@@ -1145,9 +1149,9 @@ conv_dma_kernel(const ConvParams p) {
                 for (int e = 0; e < 16; ++e) acc2[0][b][e] = smem[((partner * 2 + b) * 16 + e) * 64 + lane] + acc[0][2 + b][e];
         }
         __syncthreads();
-        conv_epilogue<BM, BN, 32, 64, THREADS>(p, acc2, smem, tid, wm, wk, m0, n0, sm);
+        conv_epilogue<BM, BN, 32, 64, THREADS>(pe, acc2, smem, tid, wm, wk, m0, n0, sm);
     } else {
-        conv_epilogue<BM, BN, 32, 128, THREADS>(p, acc, smem, tid, wm, 0, m0, n0, sm);
+        conv_epilogue<BM, BN, 32, 128, THREADS>(pe, acc, smem, tid, wm, 0, m0, n0, sm);
     }
   }
 }
