@@ -101,6 +101,9 @@ def parse(argv=None):
     ap.add_argument("--check", action="store_true", help="N > 1: compare the gathered records with single-GPU forwards on rank 0")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the real path) | gloo (rehearsal of "
                     "the N>1 control flow on a box with fewer GPUs than ranks: ranks share devices, gather goes through host)")
+    ap.add_argument("--collective", default="torch", choices=("torch", "tsod"), help="N > 1 with the nccl backend: who issues the "
+                    "all-gather of the detection records: torch.distributed's all_gather_into_tensor (default) or the C-ABI's "
+                    "tsod_allgather_f32 on a communicator of its own (include/tsod.h; the same ncclAllGather either way)")
     ap.add_argument("--rehearse-cpu", action="store_true", help="launcher / rendezvous / gather / timing / --check control flow "
                     "with fabricated records and NO GPU work (gloo; for the CPU test of the N>1 path - never a measurement)")
     return ap.parse_args(argv)
@@ -425,10 +428,17 @@ def main(argv=None):
         gathered = [torch.empty((world * B, R_POST, 6), dtype=torch.float32, device=dev if nccl else "cpu")
                     for _ in range(n_fly)] if world > 1 else None
 
+        tsod_comm = None
+        if world > 1 and nccl and args.collective == "tsod":
+            from two_stage_object_detection_amd.dist import TsodCommunicator
+            tsod_comm = TsodCommunicator(rank=rank, world=world)      # id from rank 0 over the torch.distributed group
+
         def make_step(server, depth):
             def step():
                 if world > 1:                           # the gather of step i is ordered behind step i on ITS stream
                     slot = server._next % depth
+                    if tsod_comm is not None:
+                        return server.submit(after=lambda outs: tsod_comm.all_gather(outs[4], out=gathered[slot]))
                     return server.submit(after=lambda outs: all_gather_detections(
                         outs[4] if nccl else outs[4].cpu(), out=gathered[slot]))
                 return server.submit()
@@ -528,7 +538,8 @@ def main(argv=None):
                                    + (" (BASELINE configs[4]: data-parallel, 8 images per rank)" if world > 1 and B == 8 else ""),
                        "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}",
                        "hip_graph": not args.no_graph, "autotuned_tiles": not args.no_autotune, "steps_in_flight": n_fly,
-                       "collective": None if n_gpus == 1 else f"all_gather_into_tensor [{n_gpus * B},300,6] f32 ({args.dist_backend})"},
+                       "collective": None if n_gpus == 1 else (f"tsod_allgather_f32 [{n_gpus * B},300,6] f32 (RCCL)" if args.collective == "tsod" and args.dist_backend == "nccl"
+                                                              else f"all_gather_into_tensor [{n_gpus * B},300,6] f32 ({args.dist_backend})")},
             "repeats": {"n": head["n"], "steps_each": head["steps"], "ms_per_step_median": round(head["ms_per_step"], 4),
                         "ms_per_step_min": round(head["min"], 4), "ms_per_step_max": round(head["max"], 4)},
             "serial": {"images_per_s": round(n_gpus * B / (serial["ms_per_step"] * 1e-3), 3),

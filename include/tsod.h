@@ -18,10 +18,9 @@
  *     pitch P and channel offset O lives at ((n*H + h)*W + w)*P + O + c.  Pitch/offset let a
  *     conv read or write a channel slice of a wider buffer (HarDNet's concat is free).
  *   - boxes are xyxy pixel coordinates, f32.
- *   - there is NO collective here: the one exchange of the data-parallel job (an all-gather of [B,300,6] detection
- *     records per step) is issued through torch.distributed (backend "nccl" = RCCL over xGMI), which owns the
- *     communicator; SURVEY 8(b)'s thin `tsod_allgather_f32` wrapper over ncclAllGather was dropped on purpose
- *     (two_stage_object_detection_amd/dist.py).
+ *   - the one exchange of the data-parallel job is an all-gather of [B,300,6] detection records per step.  bench.py and
+ *     dist.py issue it through torch.distributed (backend "nccl" = RCCL over xGMI), which owns its communicator;
+ *     tsod_allgather_f32 below is the same RCCL call for hosts without torch, RCCL bound at run time.
  */
 #ifndef TSOD_H
 #define TSOD_H
@@ -33,9 +32,10 @@
 extern "C" {
 #endif
 
-#define TSOD_VERSION 210 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
+#define TSOD_VERSION 220 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
                             ticket area in the workspace), pitched tsod_detections_f32, new entry points;
-                            0.2.1: two more conv tiles (bf16x3 through LDS-DMA) */
+                            0.2.1: conv tiles fed by LDS-DMA (bf16x3), balanced K schedule (split_k = -2);
+                            0.2.2: tsod_allgather_f32 + communicator helpers (RCCL bound at run time) */
 
 typedef void *tsod_stream_t; /* hipStream_t */
 
@@ -357,6 +357,18 @@ int tsod_resize_bilinear_aa_u8_f32(const uint8_t *src, int32_t H, int32_t W, int
                                    const int32_t *xfirst, const int32_t *xcount, const float *xwt, int32_t OH,
                                    int32_t OW, float mul, float *out, int64_t stride_y, int64_t stride_x,
                                    int64_t stride_c, int32_t C_out, tsod_stream_t stream);
+
+/* ---- collective: thin wrapper over ncclAllGather (RCCL over xGMI) on the caller's stream.
+ * `comm` is an ncclComm_t (from tsod_comm_init_rank below, or any communicator the host already owns); every rank sends
+ * `count_per_rank` floats and receives n_ranks * count_per_rank in rank order.  Stream-ordered, no host synchronisation.
+ * RCCL is bound at run time: TSOD_ERR_UNSUPPORTED when no librccl can be loaded.  The reference has no distributed code
+ * (nothing to match); the payload is tsod_detections_f32's fixed-size records. */
+int tsod_allgather_f32(void *comm, const float *send, float *recv, size_t count_per_rank, tsod_stream_t stream);
+/* communicator helpers for a host without torch.distributed: rank 0 makes the 128-byte id and ships it to the others by any
+ * means, then every rank calls init_rank (collective: blocks until all n_ranks have called it) */
+int tsod_comm_unique_id(void *id128);
+int tsod_comm_init_rank(void **comm, int32_t n_ranks, const void *id128, int32_t rank);
+int tsod_comm_destroy(void *comm);
 
 #ifdef __cplusplus
 }

@@ -119,3 +119,22 @@ def test_target_creator_validation():
     assert L.tsod_anchor_targets_workspace_bytes(37800, 20) >= 37800 * 4 + 80
     assert L.tsod_proposal_targets_workspace_bytes(600, 20, 128) >= 2 * 620 * 4 + 512
     assert L.tsod_anchor_targets_workspace_bytes(0, 3) == 0 and L.tsod_proposal_targets_workspace_bytes(0, 0, 128) == 0
+
+
+def test_collective_validation():
+    """tsod_allgather_f32 / tsod_comm_* (SURVEY 8(b)): arguments are checked before RCCL is even looked for, so these run
+    on the CPU box; with valid arguments and no loadable librccl the answer would be UNSUPPORTED, never a crash."""
+    import ctypes
+    L = lib()
+    comm = ctypes.c_void_p()
+    assert L.tsod_allgather_f32(None, P, P, 16, None) == INVALID
+    assert L.tsod_allgather_f32(P, None, P, 16, None) == INVALID
+    assert L.tsod_allgather_f32(P, P, P, 0, None) == INVALID
+    assert L.tsod_allgather_f32(P, ODD, P, 16, None) == ALIGNMENT
+    assert L.tsod_comm_unique_id(None) == INVALID
+    ident = ctypes.create_string_buffer(128)
+    assert L.tsod_comm_init_rank(None, 1, ident, 0) == INVALID
+    assert L.tsod_comm_init_rank(byref(comm), 0, ident, 0) == INVALID
+    assert L.tsod_comm_init_rank(byref(comm), 2, ident, 2) == INVALID
+    assert L.tsod_comm_init_rank(byref(comm), 1, None, 0) == INVALID
+    assert L.tsod_comm_destroy(None) == INVALID

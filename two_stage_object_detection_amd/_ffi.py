@@ -107,6 +107,10 @@ _SIGNATURES = {
     "tsod_proposal_targets_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "tsod_proposal_targets_f32": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_float, c_float,
                                           c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tsod_allgather_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tsod_comm_unique_id": (c_int, [c_void_p]),
+    "tsod_comm_init_rank": (c_int, [POINTER(c_void_p), c_int32, c_void_p, c_int32]),
+    "tsod_comm_destroy": (c_int, [c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -125,8 +129,8 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.tsod_version() != 210:
-            raise TsodError(f"{LIB_PATH} is version {l.tsod_version()}, this package binds version 210 of include/tsod.h: rebuild it "
+        if l.tsod_version() != 220:
+            raise TsodError(f"{LIB_PATH} is version {l.tsod_version()}, this package binds version 220 of include/tsod.h: rebuild it "
                             "(`make -C two_stage_object_detection_amd/csrc`)")
         _lib = l
     return _lib

@@ -36,6 +36,56 @@ def all_gather_detections(det_local: torch.Tensor, group=None, out: torch.Tensor
     return out
 
 
+class TsodCommunicator:
+    """An RCCL communicator owned through the C-ABI (tsod_comm_* / tsod_allgather_f32, include/tsod.h): what a host without
+    torch.distributed would use, and a second, independent way to run the job's one collective on the compute stream.
+    The 128-byte unique id is made on rank 0 and handed to the others through `exchange` (a callable bytes -> bytes that
+    returns rank 0's bytes on every rank; default: a torch.distributed broadcast on the already initialised group, else
+    identity for a single process)."""
+
+    def __init__(self, rank: int = 0, world: int = 1, exchange=None):
+        import ctypes
+        from . import _ffi
+        self._ffi, self.rank, self.world = _ffi, int(rank), int(world)
+        ident = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _ffi.check(_ffi.lib().tsod_comm_unique_id(ident))
+        raw = bytes(ident.raw)
+        if exchange is not None:
+            raw = exchange(raw)
+        elif self.world > 1:
+            t = torch.tensor(list(raw), dtype=torch.uint8)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0)
+            raw = bytes(t.cpu().tolist())
+        self._comm = ctypes.c_void_p()
+        _ffi.check(_ffi.lib().tsod_comm_init_rank(ctypes.byref(self._comm), self.world, raw, self.rank))
+
+    def all_gather(self, det_local: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """[B_local, ...] f32 on every rank -> [world * B_local, ...] in rank order, on the current stream."""
+        det_local = det_local.contiguous()
+        if det_local.dtype != torch.float32 or not det_local.is_cuda:
+            raise ValueError("tsod_allgather_f32 moves f32 device tensors")
+        if out is None:
+            out = torch.empty((self.world * det_local.shape[0],) + tuple(det_local.shape[1:]), dtype=torch.float32,
+                              device=det_local.device)
+        f = self._ffi
+        f.check(f.lib().tsod_allgather_f32(self._comm, f.ptr(det_local), f.ptr(out), det_local.numel(), f.stream_ptr()))
+        return out
+
+    def close(self):
+        if self._comm:
+            self._ffi.check(self._ffi.lib().tsod_comm_destroy(self._comm))
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 def global_roi_indices(roi_indices_local: torch.Tensor, rank: int, b_local: int) -> torch.Tensor:
     """Local image indices -> indices into the global batch."""
     return roi_indices_local + rank * b_local
