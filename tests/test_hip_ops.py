@@ -540,3 +540,28 @@ def test_conv_dual_source_is_the_sum_of_two_convs(ops, dev, C1, C2, Cout, stride
         from two_stage_object_detection_amd import _ffi
         d = _ffi.make_conv_desc(N=2, H=OH, W=OW, in_pitch=C1, segs=[(0, C1)], Cout=Cout, out_pitch=Cout, src2=(C2, C2, 0, stride2, H2, W2))
         _ffi.check(_ffi.lib().tsod_conv2d_f32(byref(d), _ffi.ptr(yn), _ffi.ptr(w), None, None, None, _ffi.ptr(out), None, 0, None))
+
+
+@pytest.mark.parametrize("shape", [(8, 50, 84, 256, 256, 3), (8, 25, 42, 2048, 512, 1), (1, 100, 167, 128, 128, 3)])
+def test_dma_conv_tiles_at_full_layer_sizes(ops, dev, shape):
+    """The LDS-DMA tiles (conv_dma_kernel) at layer sizes of BASELINE configs[1] / [4] (too large for an f64 CPU reference in
+    a unit test), through properties that do not depend on size: (1) every tile and K schedule, balanced ranges included,
+    agrees with the f32-MFMA kernel of the same layer at the accumulation-noise bar; (2) linearity in a power of two is
+    EXACT - the three bf16 pieces of 4x are 4 times the pieces of x, every product and partial sum scales exactly - so
+    conv(4x) must equal 4 conv(x) bit for bit, whatever the schedule; (3) a zero input gives exact zeros (the null / padding
+    DMAs write zeros, never stale LDS)."""
+    from two_stage_object_detection_amd._ffi import DMA_TILE_IDS
+    B, H, W, Cin, Cout, k = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    w = ops.pack_conv_weight((torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).to(dev))
+    ref = ops.conv2d_nhwc(x, w, pad=k // 2, tile=3, split_k=1)                       # f32 MFMA, whole tiles
+    tol = 3e-6 * math.sqrt(Cin * k * k) * 2 + 2e-5
+    for tile in DMA_TILE_IDS:
+        for split in (1, -1, -2, 3):
+            y = ops.conv2d_nhwc(x, w, pad=k // 2, tile=tile, split_k=split, precision=1)
+            assert (y - ref).abs().max().item() <= tol, (tile, split)
+            y4 = ops.conv2d_nhwc(x * 4.0, w, pad=k // 2, tile=tile, split_k=split, precision=1)
+            assert torch.equal(y4, y * 4.0), (tile, split, "linearity in 4 must be exact")
+    z = ops.conv2d_nhwc(torch.zeros_like(x), w, pad=k // 2, tile=DMA_TILE_IDS[0], split_k=-2, precision=1)
+    assert torch.count_nonzero(z).item() == 0
