@@ -825,17 +825,20 @@ __device__ __forceinline__ void gap_read(f32x16 &c, const bf16x8 &a, const bf16x
                  : "+v"(c), "=&v"(rd) : "v"(a), "v"(b), "v"(addr), "n"(OFF) : "memory");
 }
 
-constexpr int dma_stage_bytes(int bm, int bk) { return bm * bk * 4 + 3 * 128 * bk * 2; }
+constexpr int dma_stage_bytes(int bm, int bk, int bn = 128) { return bm * bk * 4 + 3 * bn * bk * 2; }
 
-template <int BM, int BK, int WAVES_K, int S, bool BALANCED>
-__global__ void __launch_bounds__((BM / 32) * WAVES_K * 64, (2 * S * dma_stage_bytes(BM, BK) <= 160 * 1024) ? 2 : 1)
+// WAVES_N = 2: two columns of waves, BN = 256 - both read (and split) the same activation rows, each its own 128 output
+// channels: more FLOP per byte fetched from beyond the CU (the activation stage is shared) at the same 128-row granularity
+template <int BM, int BK, int WAVES_K, int S, bool BALANCED, int WAVES_N = 1>
+__global__ void __launch_bounds__((BM / 32) * WAVES_K * WAVES_N * 64, (2 * S * dma_stage_bytes(BM, BK, 128 * WAVES_N) <= 160 * 1024) ? 2 : 1)
 conv_dma_kernel(const ConvParams p) {
-    constexpr int BN = 128, TN = 4, WAVES_M = BM / 32, WAVES = WAVES_M * WAVES_K, THREADS = WAVES * 64;
+    constexpr int BN = 128 * WAVES_N, TN = 4, WAVES_M = BM / 32, WAVES = WAVES_M * WAVES_K * WAVES_N, THREADS = WAVES * 64;
     static_assert(BK == 16 * WAVES_K, "every wave owns one 16-k chunk of the stage");
+    static_assert(WAVES_N == 1 || WAVES_K == 1, "K halves and column halves are not combined");
     constexpr int A_ROW = BK * 4, B_ROW = BK * 2;                    // bytes per LDS row (A raw f32 / one bf16 plane of B)
     constexpr int A_SLOTS = A_ROW / 16, B_SLOTS = B_ROW / 16;        // 16-byte slots per row
     constexpr int A_RPL = 256 / A_ROW, B_RPL = 256 / B_ROW;          // rows per 256-byte bank line: slot ^= (row / RPL) & (SLOTS - 1)
-    constexpr int A_BYTES = BM * A_ROW, B_PLANE = BN * B_ROW, STAGE = dma_stage_bytes(BM, BK);
+    constexpr int A_BYTES = BM * A_ROW, B_PLANE = BN * B_ROW, STAGE = dma_stage_bytes(BM, BK, BN);
     constexpr int A_RPP = 1024 / A_ROW, B_RPP = 1024 / B_ROW;        // rows per 1-KiB DMA piece
     constexpr int A_PIECES = BM / A_RPP, B_PIECES = 3 * (BN / B_RPP);
     static_assert(A_PIECES % WAVES == 0, "piece kinds per wave at compile time");
@@ -848,7 +851,7 @@ conv_dma_kernel(const ConvParams p) {
     __shared__ __align__(16) unsigned char lds[S * STAGE + (B_PAD ? 1024 : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WAVES_M, wk = wave / WAVES_M;
+    const int wm = wave % WAVES_M, wk = (wave / WAVES_M) % WAVES_K, wn = wave / (WAVES_M * WAVES_K);
     // ---- work of this workgroup: ONE (tile, K range) under the uniform schedules (the map of conv_igemm_kernel), or the K-steps
     // [w q, (w+1) q) of the launch's tile-major K-step sequence under the balanced schedule (p.sk_q > 0): a run of up to two
     // partial tiles with whole tiles between them, every workgroup the same number of K-steps whatever the tile count
@@ -901,7 +904,7 @@ conv_dma_kernel(const ConvParams p) {
     // ---- this wave's DMA pieces: q = WAVES * i + wave; piece i is an A piece for i < PA_W (= 2 for both tile shapes; the two
     // rows' state in two named structs: an array of them ends up in scratch memory behind the source select below, and a
     // scratch access is a VMEM operation that would sit in the middle of the hand-counted vmcnt)
-    static_assert(PA_W == 2, "two A pieces per wave and stage");
+    static_assert(PA_W == 1 || PA_W == 2, "one or two A pieces per wave and stage");
     struct ARow { unsigned base, base2; int ih0, iw0; };
     unsigned b_voff[P - PA_W], ldst[P];
     auto make_arow = [&](int i) {
@@ -923,7 +926,7 @@ conv_dma_kernel(const ConvParams p) {
         }
         return ar;
     };
-    const ARow ar0 = make_arow(0), ar1 = make_arow(1);
+    const ARow ar0 = make_arow(0), ar1 = make_arow(PA_W - 1);
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int q = WAVES * i + wave;
@@ -1010,7 +1013,7 @@ conv_dma_kernel(const ConvParams p) {
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int row = j * 32 + r, sl = wk * 2 + h, sw = (row / B_RPL) & (B_SLOTS - 1);
+        const int row = wn * 128 + j * 32 + r, sl = wk * 2 + h, sw = (row / B_RPL) & (B_SLOTS - 1);
         b_addr[j] = lds0 + A_BYTES + row * B_ROW + ((sl ^ sw) * 16);
     }
 
@@ -1151,7 +1154,7 @@ conv_dma_kernel(const ConvParams p) {
         __syncthreads();
         conv_epilogue<BM, BN, 32, 64, THREADS>(pe, acc2, smem, tid, wm, wk, m0, n0, sm);
     } else {
-        conv_epilogue<BM, BN, 32, 128, THREADS>(pe, acc, smem, tid, wm, 0, m0, n0, sm);
+        conv_epilogue<BM, BN, 32, 128, THREADS>(pe, acc, smem, tid, wm, wn, m0, n0, sm);
     }
   }
 }
@@ -1208,14 +1211,14 @@ const TileInfo kTiles[TSOD_TILE_COUNT] = {
     {64, 64, 64, 8, 1.40f, 32, 1, 0},   {128, 64, 128, 4, 1.35f, 32, 1, 0}, {128, 64, 256, 4, 1.12f, 32, 1, 1}, {64, 128, 256, 4, 1.12f, 32, 1, 1},
     {128, 128, 256, 2, 1.02f, 32, 1, 1},
     {128, 128, 256, 2, 0.80f, 16, 4, 1, 1}, {64, 128, 256, 1, 0.95f, 32, 3, 1, 1}, {256, 128, 512, 1, 0.72f, 16, 4, 1, 1},
-    {64, 128, 256, 2, 0.98f, 32, 2, 1, 1}};
+    {64, 128, 256, 2, 0.98f, 32, 2, 1, 1}, {128, 256, 512, 1, 0.74f, 16, 4, 1, 1}};
 // bf16x3 = 1: the tile also exists as a bf16x3 variant (three bf16 planes per operand fit the 64 KB of static LDS)
 
 // workgroups per CU: the f32 figure (VGPR / LDS bound), for bf16x3 additionally capped by its larger LDS footprint
 int residency(int tile, int prec) {
     const TileInfo &t = kTiles[tile];
     if (!prec) return t.resident;
-    const int lds = t.dma ? t.nbuf * dma_stage_bytes(t.bm, t.bk) : t.nbuf * 3 * (t.bm + t.bn) * (t.bk / 2) * 4;
+    const int lds = t.dma ? t.nbuf * dma_stage_bytes(t.bm, t.bk, t.bn) : t.nbuf * 3 * (t.bm + t.bn) * (t.bk / 2) * 4;
     const int fit = 160 * 1024 / lds;
     return fit < t.resident ? (fit < 1 ? 1 : fit) : t.resident;
 }
@@ -1396,12 +1399,12 @@ Sched resolve(const tsod_conv2d_desc *d) {
     return best;
 }
 
-template <int BM, int BK, int WAVES_K, int S>
+template <int BM, int BK, int WAVES_K, int S, int WAVES_N = 1>
 void launch_dma_tile(const ConvParams &p, int grid, hipStream_t s) {
     if (p.sk_q > 0)
-        hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S, true>), dim3(grid), dim3((BM / 32) * WAVES_K * 64), 0, s, p);
+        hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S, true, WAVES_N>), dim3(grid), dim3((BM / 32) * WAVES_K * WAVES_N * 64), 0, s, p);
     else
-        hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S, false>), dim3(grid), dim3((BM / 32) * WAVES_K * 64), 0, s, p);
+        hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S, false, WAVES_N>), dim3(grid), dim3((BM / 32) * WAVES_K * WAVES_N * 64), 0, s, p);
 }
 
 template <int BM, int BN, int WM, int WN, int MW, int NBUF = 2, int BK = 32, int PREC = 0>
@@ -1516,6 +1519,7 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
             case TSOD_TILE_D64x128: launch_dma_tile<64, 32, 2, 3>(p, sc.grid, s); break;
             case TSOD_TILE_D256x128: launch_dma_tile<256, 16, 1, 4>(p, sc.grid, s); break;
             case TSOD_TILE_D64x128_S2: launch_dma_tile<64, 32, 2, 2>(p, sc.grid, s); break;
+            case TSOD_TILE_D128x256: launch_dma_tile<128, 16, 1, 4, 2>(p, sc.grid, s); break;
             default: launch_tile<64, 64, 32, 32, 2, 2, 32, 1>(p, sc.grid, s); break;      // TSOD_TILE_64x64 (two LDS stages)
         }
         return tsod_launch_status();
