@@ -138,3 +138,27 @@ def test_collective_validation():
     assert L.tsod_comm_init_rank(byref(comm), 2, ident, 2) == INVALID
     assert L.tsod_comm_init_rank(byref(comm), 1, None, 0) == INVALID
     assert L.tsod_comm_destroy(None) == INVALID
+
+
+def test_balanced_schedule_and_dma_tile_gates_are_host_side():
+    """split_k = -2 (balanced K ranges) and the TSOD_TILE_D* tiles (conv_dma_kernel) are refused on the host, before any launch,
+    whenever they cannot run the problem: f32 arithmetic, a tile that does not know the schedule, a channel count that is not
+    whole K stages, concatenated inputs.  And where they can, the resolver reports them with a workspace that holds two slabs
+    per workgroup behind the fixed-size ticket area."""
+    L = lib()
+    PREC_BF16X3 = 1
+    d = _desc(tile=17, split_k=-2, precision=PREC_BF16X3)                       # d128x128, balanced: 64 channels = 4 stages of 16
+    t, s = c_int32(), c_int32()
+    assert L.tsod_conv2d_resolve(byref(d), byref(t), byref(s)) == OK and (t.value, s.value) == (17, -2)
+    ws = L.tsod_conv2d_workspace_bytes(byref(d))
+    assert ws > 256 * 1024 and (ws - 256 * 1024) % (2 * 128 * 128 * 4) == 0
+    assert L.tsod_conv2d_f32(byref(d), P, P, None, None, None, P, None, 0, None) == WORKSPACE
+    assert L.tsod_conv2d_resolve(byref(_desc(tile=17, split_k=-2)), byref(t), byref(s)) == UNSUPPORTED            # f32
+    assert L.tsod_conv2d_resolve(byref(_desc(tile=8, split_k=-2, precision=PREC_BF16X3)), byref(t), byref(s)) == UNSUPPORTED
+    assert L.tsod_conv2d_resolve(byref(_desc(tile=17, split_k=1, precision=PREC_BF16X3, in_pitch=72, segs=[(0, 72)])),
+                                 byref(t), byref(s)) == UNSUPPORTED                                                # 72 % 16 != 0
+    assert L.tsod_conv2d_resolve(byref(_desc(tile=18, split_k=1, precision=PREC_BF16X3, in_pitch=128, segs=[(0, 32), (64, 32)])),
+                                 byref(t), byref(s)) == UNSUPPORTED                                                # two segments
+    assert L.tsod_conv2d_resolve(byref(_desc(split_k=-3)), byref(t), byref(s)) == INVALID
+    auto = _desc(precision=PREC_BF16X3)                                          # the cost model's pick is one of the bf16x3 tiles
+    assert L.tsod_conv2d_resolve(byref(auto), byref(t), byref(s)) == OK and t.value in _ffi.BF16X3_TILE_IDS
