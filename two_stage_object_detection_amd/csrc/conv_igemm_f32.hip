@@ -755,7 +755,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
 //     the DMA writes zeros (scripts/micro/lds_dma_oob.hip).  The wave that OWNS a fragment splits it into the three bf16
 //     pieces, in the shadow of its own MFMAs: no element is split twice, and there are 44 VALU per 24 MFMAs.
 //   * B (weights) is the pre-split image of tsod_pack_conv_weight_bf16x3 and lands in three unpadded planes.
-//   * Wave tile 32 x 128 (BN = 128): WAVES_M = BM / 32 waves along M, and for the small tile WAVES_K = 2 waves along K
+//   * Wave tile 32 x 128 (BN = 128, or 256 with two columns of waves): WAVES_M = BM / 32 waves along M, and for the small tile WAVES_K = 2 waves along K
 //     inside a stage (each owns one 16-k chunk; the halves are exchanged through LDS before the epilogue, every wave then
 //     finishing 32 x 64).  One phase per stage and wave; an S-deep ring of stages; vmcnt / lgkmcnt counted by hand (the
 //     compiler sees none of these memory operations; what it must not do is keep LDS reads of its own pending in the loop).
@@ -901,7 +901,7 @@ conv_dma_kernel(const ConvParams p) {
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)lds;
     const int kgroups = p.K / 8;
 
-    // ---- this wave's DMA pieces: q = WAVES * i + wave; piece i is an A piece for i < PA_W (= 2 for both tile shapes; the two
+    // ---- this wave's DMA pieces: q = WAVES * i + wave; piece i is an A piece for i < PA_W (1 or 2 for every tile shape; the
     // rows' state in two named structs: an array of them ends up in scratch memory behind the source select below, and a
     // scratch access is a VMEM operation that would sit in the middle of the hand-counted vmcnt)
     static_assert(PA_W == 1 || PA_W == 2, "one or two A pieces per wave and stage");
