@@ -32,10 +32,11 @@
 extern "C" {
 #endif
 
-#define TSOD_VERSION 220 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
+#define TSOD_VERSION 230 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
                             ticket area in the workspace), pitched tsod_detections_f32, new entry points;
                             0.2.1: conv tiles fed by LDS-DMA (bf16x3), balanced K schedule (split_k = -2);
-                            0.2.2: tsod_allgather_f32 + communicator helpers (RCCL bound at run time) */
+                            0.2.2: tsod_allgather_f32 + communicator helpers (RCCL bound at run time);
+                            0.3.0: tsod_bbox2loc_f32; a dual-source conv's c2 must be whole K-steps of the tile */
 
 typedef void *tsod_stream_t; /* hipStream_t */
 
@@ -115,7 +116,9 @@ typedef struct tsod_conv2d_desc {
      * bottleneck's last 1x1 conv and its projection shortcut (models/resnet.py:70-74 with :114-116) as ONE GEMM
      *   out = act( [y | x_strided] . [W3*s3 | Wd*sd]^T + (b3 + bd) )
      * (the caller folds both BN scales into the stacked weights [Cout][KH*KW*Cin + c2] and adds the shifts).
-     * Requires one channel segment, Cin % 32 == 0 and KH*KW*Cin % 32 == 0 (K-steps never straddle the sources). */
+     * Requires one channel segment and Cin, KH*KW*Cin AND c2 multiples of the tile's K-step (32; 64 for the _K64 tiles; the
+     * stage of the TSOD_TILE_D* tiles): K-steps never straddle the sources nor run past c2.  A named tile that does not
+     * divide them returns TSOD_ERR_UNSUPPORTED; TSOD_TILE_AUTO only considers tiles that do. */
     int32_t c2, in2_pitch, in2_off, stride2, H2, W2;
 } tsod_conv2d_desc;
 
@@ -218,6 +221,11 @@ int tsod_enumerate_anchors_f32(const float *anchor_base, int32_t A, int32_t Hf, 
 
 /* utils/loc_bbox_iou.py:29-61 as a stand-alone op: src [n][4] xyxy, loc [n][4] (dx,dy,dw,dh) -> out [n][4]. */
 int tsod_loc2bbox_f32(const float *src, const float *loc, int64_t n, float *out, tsod_stream_t stream);
+
+/* utils/loc_bbox_iou.py:63-88 (bbox2loc) as a stand-alone op, the inverse of loc2bbox: src [n][4], dst [n][4] xyxy ->
+ * out [n][4] = ((cx_d - cx_s) / w_s, (cy_d - cy_s) / h_s, log(w_d / w_s), log(h_d / h_s)), w_s / h_s floored at f32 eps.
+ * The same device function the two target creators below call. */
+int tsod_bbox2loc_f32(const float *src, const float *dst, int64_t n, float *out, tsod_stream_t stream);
 
 /* Per-image stable descending top-k.  Replaces torch.argsort(score, descending=True)[:n_pre] and
  * the gathers at nets/rpn.py:56-61.  keys [B][n]; entries equal to -inf are "filtered out" and

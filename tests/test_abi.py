@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_symbols():
         assert hasattr(raw, name), name
     lib = _ffi.lib()
-    assert lib.tsod_version() == 220
+    assert lib.tsod_version() == 230
     assert lib.tsod_status_str(0) == b"ok"
     assert b"workspace" in lib.tsod_status_str(-4)
 

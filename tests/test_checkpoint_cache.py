@@ -93,6 +93,16 @@ def test_trainer_checkpoint_to_hip_forward_with_packed_cache(dev, tmp_path, back
         got3 = m2(x.to(dev))[1].cpu()
         assert (got3 - got2[1] - 0.5).abs().max().item() < 1e-4        # the edited bias is what runs
 
+        # same weights, other anchors (not in the state_dict; the RPN entry stores the base anchors): another file, never a
+        # hit that would serve the first detector's anchors
+        m3 = FasterRCNN(20, backbone=backbone, anchor_scales=[4, 8, 16]).to(dev).eval()
+        m3.load_trainer_checkpoint(str(ckpt))
+        assert weight_cache.cache_path(str(cache), m3) != weight_cache.cache_path(str(cache), m1)
+        assert m3.use_packed_cache(str(cache)) == "miss"
+        base3 = m3.rpn._pack(dev)[1].cpu()
+        assert torch.equal(base3, torch.as_tensor(m3.rpn.anchor_base, dtype=torch.float32))
+        assert not torch.equal(base3, torch.as_tensor(m1.rpn.anchor_base, dtype=torch.float32))
+
     # tile tables ride along, keyed by geometry + device
     plan = m1.extractor._plan_for(x.to(dev))
     p = weight_cache.save_tiles(m1, str(cache), x.shape, dev, plan.export_tiles())

@@ -84,6 +84,9 @@ def test_bench_launcher_starts_the_ranks_itself():
     assert line["check"]["ok"] is True and line["check"]["images"] == 6 and line["check"]["records_unmatched"] == 0
     assert line["check"]["max_abs_box_on_matched"] == 0.0 and line["check"]["images_off"] == []
     assert line["steps"] == 3 and line["scaling"] == "weak"
+    # start-up protocol of the N>1 run: rank 0's tile table + head choices reached every rank as JSON
+    assert line["tiles_broadcast_ok_per_rank"] == [True, True] and line["check"]["matching"] == "position-wise"
+    assert line["check"]["bit_exact"] is True
 
 
 def test_bench_refuses_more_nccl_ranks_than_gpus(monkeypatch):
@@ -96,3 +99,18 @@ def test_bench_refuses_more_nccl_ranks_than_gpus(monkeypatch):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert "needs a GPU" in (r.stdout + r.stderr) or "visible GPU" in (r.stdout + r.stderr)
+
+
+def test_tsod_communicator_every_rank_raises_when_rank0_could_not_make_the_id():
+    """dist.TsodCommunicator ships rank 0's status WITH the unique id: a rank that receives a failed status raises (instead of
+    entering ncclCommInitRank and blocking for a rank 0 that already raised)."""
+    from two_stage_object_detection_amd._ffi import TsodError
+    from two_stage_object_detection_amd.dist import TsodCommunicator
+    seen = {}
+
+    def exchange(raw):
+        seen["len"] = len(raw)
+        return bytes(128) + bytes([2])                 # what rank 0 would broadcast after TSOD_ERR_UNSUPPORTED (-2)
+    with pytest.raises(TsodError, match="rank 0"):
+        TsodCommunicator(rank=1, world=2, exchange=exchange)
+    assert seen["len"] == 129

@@ -542,6 +542,48 @@ def test_conv_dual_source_is_the_sum_of_two_convs(ops, dev, C1, C2, Cout, stride
         _ffi.check(_ffi.lib().tsod_conv2d_f32(byref(d), _ffi.ptr(yn), _ffi.ptr(w), None, None, None, _ffi.ptr(out), None, 0, None))
 
 
+@pytest.mark.parametrize("C1,C2", [(64, 48), (64, 32), (32, 96)])
+def test_conv_dual_source_second_source_must_be_whole_ksteps(ops, dev, C1, C2):
+    """The stacked-K GEMM's K-steps must not run past the second source's c2 channels (the uniform-tap loader has no k < K
+    mask): a tile whose K-step does not divide c2 is REFUSED when named (TSOD_ERR_UNSUPPORTED) and never picked by
+    TSOD_TILE_AUTO; every tile that does divide it matches the two f64 CPU convolutions added up (c2 = 48 only fits the
+    16-float stages of the LDS-DMA tiles; c2 = 32 fits the 32-float tiles but not the _K64 ones)."""
+    from two_stage_object_detection_amd._ffi import BF16X3_TILE_IDS, TILE_IDS, DMA_TILE_IDS, TsodError
+    g = torch.Generator().manual_seed(35)
+    H2, W2, Cout = 11, 13, 96
+    y = torch.randn(2, C1, H2, W2, generator=g)
+    x = torch.randn(2, C2, H2, W2, generator=g)
+    w3 = torch.randn(Cout, C1, 1, 1, generator=g) / math.sqrt(C1)
+    wd = torch.randn(Cout, C2, 1, 1, generator=g) / math.sqrt(C2)
+    ref = (F.conv2d(y.double(), w3.double()) + F.conv2d(x.double(), wd.double())).float()
+    yn, xn = ops.nchw_to_nhwc(y.to(dev)), ops.nchw_to_nhwc(x.to(dev))
+    w = torch.cat([w3.flatten(1), wd.flatten(1)], dim=1).contiguous().to(dev)
+    tol = 3e-6 * math.sqrt(C1 + C2) + 1e-5
+    bk_of = {10: 64, 11: 64, 17: 16, 19: 16, 21: 16}                       # K-step of a tile (floats); 32 for the others
+    ran = refused = 0
+    for prec, tiles in ((0, TILE_IDS), (1, BF16X3_TILE_IDS)):
+        for tile in tiles:
+            bk = bk_of.get(tile, 32)
+            fits = C1 % bk == 0 and C2 % bk == 0
+            for split in (1, -1, 2):
+                if fits:
+                    out = ops.conv2d_nhwc(yn, w, segs=[(0, C1)], tile=tile, split_k=split, precision=prec, x2=xn)
+                    assert (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item() <= tol, (tile, split, prec)
+                    ran += 1
+                else:
+                    with pytest.raises(TsodError, match="unsupported|UNSUPPORTED"):
+                        ops.conv2d_nhwc(yn, w, segs=[(0, C1)], tile=tile, split_k=split, precision=prec, x2=xn)
+                    refused += 1
+        any_fits = any(C1 % bk_of.get(t, 32) == 0 and C2 % bk_of.get(t, 32) == 0 for t in tiles)
+        if any_fits:                                                         # AUTO only considers tiles that fit
+            out = ops.conv2d_nhwc(yn, w, segs=[(0, C1)], precision=prec, x2=xn)
+            assert (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item() <= tol, ("auto", prec)
+        else:
+            with pytest.raises(TsodError, match="unsupported|UNSUPPORTED"):
+                ops.conv2d_nhwc(yn, w, segs=[(0, C1)], precision=prec, x2=xn)
+    assert ran > 0 and refused > 0
+
+
 @pytest.mark.parametrize("shape", [(8, 50, 84, 256, 256, 3), (8, 25, 42, 2048, 512, 1), (1, 100, 167, 128, 128, 3)])
 def test_dma_conv_tiles_at_full_layer_sizes(ops, dev, shape):
     """The LDS-DMA tiles (conv_dma_kernel) at layer sizes of BASELINE configs[1] / [4] (too large for an f64 CPU reference in

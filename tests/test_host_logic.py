@@ -154,6 +154,10 @@ def test_loading_weights_through_the_detector_invalidates_every_packed_copy(tmp_
     import copy
     m2 = copy.deepcopy(m)                                                # plans / packed weights are not copied
     assert not m2.extractor._plans and m2.state_dict().keys() == m.state_dict().keys()
+    assert m2._uid != m._uid                                             # its own scratch ownership (arena slabs / tickets)
+    import pickle
+    m3 = pickle.loads(pickle.dumps(m))
+    assert len({m._uid, m2._uid, m3._uid}) == 3
 
 
 def test_plan_cache_is_lru_bounded():
@@ -192,5 +196,44 @@ def test_weight_cache_hash_and_plain_data_roundtrip(tmp_path):
     back = wc._from_state(torch.load(path, weights_only=True)["e"], "cpu")
     assert isinstance(back, tuple) and isinstance(back[0], PackedConv) and back[2:] == (36, 18)
     assert torch.equal(back[0].w, pc.w) and back[0].scale is None and back[0].slope == 0.25 and back[0].out_hw(5, 7) == (5, 7)
-    assert wc.cache_path(str(tmp_path), m).endswith(f"hardnet39-{wc.state_dict_hash(m.state_dict())}.tsodpack")
+    # the file name hashes the state_dict AND what the packed entries depend on besides it (anchors, stride, RoI op, BN eps)
+    p0 = wc.cache_path(str(tmp_path), m)
+    assert os.path.basename(p0).startswith("hardnet39-") and p0.endswith(".tsodpack") and p0 == wc.cache_path(str(tmp_path), m)
+    torch.manual_seed(1)
+    m_anchor = FasterRCNN(num_classes=3, anchor_scales=[4, 8, 16]).eval()
+    m_anchor.load_state_dict(m.state_dict())
+    assert wc.state_dict_hash(m_anchor.state_dict()) == wc.state_dict_hash(m.state_dict())
+    assert wc.cache_path(str(tmp_path), m_anchor) != p0                # same weights, other base anchors: another file
+    eps0 = m.extractor.base[0].norm.eps
+    m.extractor.base[0].norm.eps = eps0 * 2
+    assert wc.cache_path(str(tmp_path), m) != p0                       # BN eps is folded into the packed weights
+    m.extractor.base[0].norm.eps = eps0
     assert wc.load_packed(m, str(tmp_path), "cpu") is False          # nothing cached yet: the model is left alone
+
+
+def test_bench_compare_records_is_position_wise():
+    """bench.py --check (default for N > 1): all ranks run rank 0's tile tables, so records are compared position by position."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    g = torch.Generator().manual_seed(4)
+    ref = torch.rand(3, 300, 6, generator=g) * 100
+    ref[..., 5] = torch.randint(0, 81, (3, 300), generator=g).float()
+    rep = bench.compare_records(ref.clone(), ref)
+    assert rep["ok"] and rep["bit_exact"] and rep["records_unmatched"] == 0 and rep["images"] == 3
+    near = ref.clone()
+    near[1, 7, 2] += 5e-4
+    rep = bench.compare_records(near, ref)
+    assert rep["ok"] and not rep["bit_exact"] and 4e-4 < rep["max_abs_box_on_matched"] < 6e-4
+    swapped = ref.clone()
+    swapped[2, [10, 11]] = swapped[2, [11, 10]]
+    rep = bench.compare_records(swapped, ref)
+    assert not rep["ok"] and rep["images_off"] == [2] and rep["records_unmatched"] == 2    # a set-based check would pass this
+    cls = ref.clone()
+    cls[0, 0, 5] += 1
+    rep = bench.compare_records(cls, ref)
+    assert not rep["ok"] and rep["class_mismatch_on_matched"] == 1 and rep["images_off"] == [0]
+    nan = ref.clone()
+    nan[0, 3, 4] = float("nan")
+    assert not bench.compare_records(nan, ref)["ok"]

@@ -76,6 +76,7 @@ _SIGNATURES = {
                                          c_void_p, c_void_p]),
     "tsod_enumerate_anchors_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "tsod_loc2bbox_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "tsod_bbox2loc_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "tsod_sort_topk_desc_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p]),
     "tsod_nms_workspace_bytes": (c_size_t, [c_int32, c_int32]),
@@ -129,8 +130,8 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.tsod_version() != 220:
-            raise TsodError(f"{LIB_PATH} is version {l.tsod_version()}, this package binds version 220 of include/tsod.h: rebuild it "
+        if l.tsod_version() != 230:
+            raise TsodError(f"{LIB_PATH} is version {l.tsod_version()}, this package binds version 230 of include/tsod.h: rebuild it "
                             "(`make -C two_stage_object_detection_amd/csrc`)")
         _lib = l
     return _lib

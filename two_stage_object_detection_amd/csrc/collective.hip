@@ -35,9 +35,17 @@ const Rccl &rccl() {
     static std::once_flag once;
     std::call_once(once, [] {
         void *h = nullptr;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        // first: an RCCL this process has ALREADY mapped (torch.distributed's, whatever path it came from) - RTLD_NOLOAD only
+        // succeeds for a library that is resident, so the process never ends up with two copies
+        for (const char *name : names) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             if (h) break;
+        }
+        if (!h && dlsym(RTLD_DEFAULT, "ncclAllGather")) h = dlopen(nullptr, RTLD_NOW);   // loaded globally under another soname
+        for (const char *name : names) {
+            if (h) break;
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!h) return;
         r.get_unique_id = (fn_get_unique_id)dlsym(h, "ncclGetUniqueId");

@@ -167,6 +167,32 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
         // XCDs (private L2s): slabs are stored WRITE-THROUGH (sc1, 16 bytes per lane: each accumulator block goes through the
         // wave's LDS patch so that a lane owns 4 consecutive columns), every storing wave drains its stores, one lane adds
         // to the ticket at agent scope, and the reducer reads EVERY slab byte with sc1 loads (never through a stale L1/L2 line).
+        //
+        // Why this is a valid hand-off on gfx950 (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup
+        // visibility"; cdna_hip_programming.md Guideline 16).  What can go stale on this chip is (a) a line in the READING
+        // CU's vector L1, which no other CU's store ever refreshes, and (b) a line in an XCD's L2 when the producer sits on
+        // another XCD (the L2s are not coherent with each other).  The guide's "valid forms" allow sc1 loads IN PLACE OF the
+        // consumer's agent-scope acquire when four conditions hold, and they hold here by construction:
+        //   (1) EVERY load of the handed-off bytes is a buffer_load ... sc1 to registers (buffer_load4_aux<AUX_SC1> below is
+        //       the only reader of the slab area): sc1 loads bypass the L1 and are served at agent scope, so (a) cannot occur;
+        //   (2) the producer stored EVERY one of those bytes sc1 (raw_buffer_store_b128 with AUX_SC1 just below): a
+        //       write-through store that leaves the producer XCD's L2 for memory and DROPS the line there (guide, stores
+        //       table), so no XCD's L2 keeps a private dirty copy, which removes (b);
+        //   (3) every storing wave runs `s_waitcnt vmcnt(0)` after its stores (the asm statement below - inline asm, so the
+        //       compiler hazard that drops a wait in front of a provably empty scoreboard cannot apply), and the ONE ticket
+        //       add that signals for the whole workgroup comes behind the workgroup barrier that follows those waits;
+        //   (4) the shape is the guide's first measured row: one lane of each storing workgroup adds to ONE unsharded
+        //       agent-scope counter (a returning atomic, executed at the memory side), the consumer is "the workgroup whose
+        //       add came last, told by the value its add returned"; the adding wave loads only after its add has returned
+        //       (data dependence through s_flag), the other waves after a workgroup barrier that wave joins; hipMalloc
+        //       memory (torch's allocator); 16-byte sc1 stores and loads.  One cell differs: that row was measured with one
+        //       workgroup per CU and these tiles run 1-6 per CU.  Residency does not enter the argument above (neither L1
+        //       bypass nor write-through depends on it); tests/test_hip_ops.py::test_conv_kslice_reduce_is_deterministic_
+        //       under_load holds tiles at 2-6 workgroups per CU to bit-identical results over hundreds of launches with L2
+        //       eviction in between.  The guide labels this form "measured, not an architectural guarantee"; the
+        //       architectural form would add fence(acquire, "agent") (buffer_inv sc1, ~1.7 us) on the last arriver, which
+        //       protects plain loads - there are none.
+        // The atomic itself is relaxed: ordering against the slab stores comes from (3), not from the atomic's semantics.
         constexpr int AUX_SC1 = 16;
         const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc((void *)p.partial, (short)0, (int)p.part_bytes, 0x00020000);
         const int rem = sm.ticket;
@@ -204,7 +230,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
         }
         __syncthreads();
         if (s_flag[0] == 0) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");             // no instruction: keeps the slab loads below the ticket
+        // compiler-only ordering (emits no instruction): the sc1 slab loads below must not be hoisted above the barrier that
+        // publishes the ticket result; the hardware side of the acquire is condition (1) of the comment at the top
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, (short)0, (int)p.out_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), (short)0,
                                                                                (int)(p.res ? p.res_bytes : 0u), 0x00020000);
@@ -1265,14 +1293,16 @@ int desc_cin(const tsod_conv2d_desc *d) {
 // contraction length: the filter taps over the first source + the second source's channels
 int desc_k(const tsod_conv2d_desc *d) { return d->KH * d->KW * desc_cin(d) + (d->c2 > 0 ? d->c2 : 0); }
 
-// a tile's K-step must divide both the channel count (uniform taps) and K1 when there is a second source; the LDS-DMA
-// tiles need that always (a stage lies inside one filter tap of one channel segment, K is whole stages)
+// a tile's K-step must divide the channel count (uniform taps), K1 AND the second source's channel count when there is a
+// second source (the uniform-tap loader has no k < K mask: a K-step that ran past in2's c2 channels would read the next
+// pixel's channels and the next weight row); the LDS-DMA tiles need that always (a stage lies inside one filter tap of one
+// channel segment, K is whole stages)
 bool tile_ok_for(const tsod_conv2d_desc *d, int tile) {
     const int bk = kTiles[tile].bk;
     if (kTiles[tile].dma)
         return d->n_seg == 1 && desc_cin(d) % bk == 0 && (d->c2 <= 0 || d->c2 % bk == 0);
     if (d->c2 <= 0) return true;
-    return desc_cin(d) % bk == 0 && (d->KH * d->KW * desc_cin(d)) % bk == 0;
+    return desc_cin(d) % bk == 0 && (d->KH * d->KW * desc_cin(d)) % bk == 0 && d->c2 % bk == 0;
 }
 
 int g_cu_count = 0;
@@ -1381,7 +1411,7 @@ Sched resolve(const tsod_conv2d_desc *d) {
         if (d->tile != TSOD_TILE_AUTO && d->tile != t) continue;
         if (d->precision && !kTiles[t].bf16x3) continue;
         if (!d->precision && kTiles[t].dma) continue;
-        if (!tile_ok_for(d, t) && (d->tile != t || kTiles[t].dma)) continue;
+        if (!tile_ok_for(d, t)) continue;        // (also an explicitly named tile: the caller gets TSOD_ERR_UNSUPPORTED)
         if (d->split_k != 0) {
             const Sched s = make_sched(d, t, d->split_k);
             if (s.cost < best.cost) best = s;
@@ -1496,7 +1526,7 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
     const Sched sc = resolve(d);
     TSOD_REQUIRE(sc.cost < 1e299, TSOD_ERR_UNSUPPORTED);        // the named tile cannot run this problem (LDS-DMA tiles: tile_ok_for)
     p.uniform_tap = (d->n_seg == 1 && p.Cin % kTiles[sc.tile].bk == 0) ? 1 : 0;
-    TSOD_REQUIRE(p.c2 == 0 || (p.uniform_tap && p.K1 % kTiles[sc.tile].bk == 0), TSOD_ERR_UNSUPPORTED);
+    TSOD_REQUIRE(p.c2 == 0 || (p.uniform_tap && p.K1 % kTiles[sc.tile].bk == 0 && p.c2 % kTiles[sc.tile].bk == 0), TSOD_ERR_UNSUPPORTED);
     p.ksteps = (p.K + kTiles[sc.tile].bk - 1) / kTiles[sc.tile].bk;
     p.tiles_m = sc.tiles_m; p.tiles_n = sc.tiles_n;
     p.dp_tiles = sc.dp_tiles; p.split = sc.split; p.ksteps_per_split = sc.ksteps_per_split; p.sk_q = sc.sk_q;

@@ -226,6 +226,13 @@ proposal_select_kernel(const float4 *__restrict__ roi, int R, const float4 *__re
 
 size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+// utils/loc_bbox_iou.py:63-88 as a stand-alone op: one thread per box pair
+__global__ void __launch_bounds__(256)
+bbox2loc_kernel(const float4 *__restrict__ src, const float4 *__restrict__ dst, long n, float4 *__restrict__ out) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+        out[t] = bbox2loc_dev(src[t], dst[t]);
+}
+
 }  // namespace
 
 extern "C" size_t tsod_anchor_targets_workspace_bytes(int32_t A, int32_t G) {
@@ -287,5 +294,14 @@ extern "C" int tsod_proposal_targets_f32(const float *roi, int32_t R, const floa
                        reinterpret_cast<const long long *>(gt_label), max_iou, assign, n_sample, pos_per_image, pos_iou_thresh,
                        neg_iou_thresh_high, neg_iou_thresh_low, reinterpret_cast<float4 *>(sample_roi),
                        reinterpret_cast<float4 *>(gt_roi_loc), reinterpret_cast<long long *>(gt_roi_label), neg_orig, counts);
+    return tsod_launch_status();
+}
+
+extern "C" int tsod_bbox2loc_f32(const float *src, const float *dst, int64_t n, float *out, tsod_stream_t stream) {
+    TSOD_REQUIRE(src && dst && out && n > 0, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(tsod_aligned16(src) && tsod_aligned16(dst) && tsod_aligned16(out), TSOD_ERR_ALIGNMENT);
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bbox2loc_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), reinterpret_cast<const float4 *>(src),
+                       reinterpret_cast<const float4 *>(dst), (long)n, reinterpret_cast<float4 *>(out));
     return tsod_launch_status();
 }

@@ -39,8 +39,8 @@ def all_gather_detections(det_local: torch.Tensor, group=None, out: torch.Tensor
 class TsodCommunicator:
     """An RCCL communicator owned through the C-ABI (tsod_comm_* / tsod_allgather_f32, include/tsod.h): what a host without
     torch.distributed would use, and a second, independent way to run the job's one collective on the compute stream.
-    The 128-byte unique id is made on rank 0 and handed to the others through `exchange` (a callable bytes -> bytes that
-    returns rank 0's bytes on every rank; default: a torch.distributed broadcast on the already initialised group, else
+    The 128-byte unique id (+ one status byte) is made on rank 0 and handed to the others through `exchange` (a callable
+    bytes -> bytes that returns rank 0's bytes on every rank; default: a torch.distributed broadcast on the already initialised group, else
     identity for a single process)."""
 
     def __init__(self, rank: int = 0, world: int = 1, exchange=None):
@@ -48,9 +48,10 @@ class TsodCommunicator:
         from . import _ffi
         self._ffi, self.rank, self.world = _ffi, int(rank), int(world)
         ident = ctypes.create_string_buffer(128)
-        if self.rank == 0:
-            _ffi.check(_ffi.lib().tsod_comm_unique_id(ident))
-        raw = bytes(ident.raw)
+        # rank 0's status travels WITH the id (one extra byte): when it could not make one (no loadable librccl ->
+        # TSOD_ERR_UNSUPPORTED) every rank raises, instead of rank 0 raising alone and the others blocking in the broadcast
+        rc0 = _ffi.lib().tsod_comm_unique_id(ident) if self.rank == 0 else 0
+        raw = bytes(ident.raw) + bytes([min(255, -int(rc0))])
         if exchange is not None:
             raw = exchange(raw)
         elif self.world > 1:
@@ -59,6 +60,9 @@ class TsodCommunicator:
                 t = t.cuda()
             dist.broadcast(t, src=0)
             raw = bytes(t.cpu().tolist())
+        if len(raw) > 128 and raw[128] != 0:
+            _ffi.check(-int(raw[128]), "tsod_comm_unique_id on rank 0")
+        raw = raw[:128]
         self._comm = ctypes.c_void_p()
         _ffi.check(_ffi.lib().tsod_comm_init_rank(ctypes.byref(self._comm), self.world, raw, self.rank))
 

@@ -86,6 +86,11 @@ def weights_bf16x3(pc) -> torch.Tensor:
     if w3 is None:
         from . import hip_ops
         w3 = pc.w3 = hip_ops.pack_conv_weight_bf16x3(pc.w)
+        # the image is shared by every plan, in-flight slot and stream of the owner: it must be complete before a consumer on
+        # ANOTHER stream can see the attribute (one host wait per layer, at build time; illegal - and never needed, the
+        # warm-up forwards of a capture run first - while the stream is being captured)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(w3.device).synchronize()
     return w3
 
 

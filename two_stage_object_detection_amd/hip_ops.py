@@ -133,28 +133,39 @@ _W3_CACHE: dict = {}
 
 
 def _w3_for(w_packed: torch.Tensor) -> torch.Tensor:
-    """Pre-split image of a weight tensor for the tensor-level wrapper (the engine keeps its own per layer)."""
-    version = 0 if w_packed.is_inference() else w_packed._version       # inference tensors carry no version counter
-    key = (w_packed.data_ptr(), tuple(w_packed.shape), version)
+    """Pre-split image of a weight tensor for the tensor-level wrapper when the caller did not bring one (``w3=`` of
+    conv2d_nhwc; the engine, the RPN and the RoI head keep theirs beside the packed f32 weights).
+    Cached per (storage address, shape, version counter); the entry holds the tensor's BASE strongly, so the address cannot be
+    handed to another tensor while the entry lives, and a fresh ``w.view(...)`` of the same weights (a new Python object on
+    every call) hits.  Inference tensors carry no version counter - an in-place edit would be invisible - so they are
+    never cached: packed on every call (correct, slower; bring ``w3=`` on a hot path)."""
+    if w_packed.is_inference():
+        return pack_conv_weight_bf16x3(w_packed)
+    key = (w_packed.data_ptr(), tuple(w_packed.shape), w_packed._version)
     hit = _W3_CACHE.get(key)
-    if hit is None or hit[0]() is not w_packed:
-        import weakref
-        if len(_W3_CACHE) > 64:
+    if hit is None:
+        if len(_W3_CACHE) >= 64:
             _W3_CACHE.clear()
-        hit = _W3_CACHE[key] = (weakref.ref(w_packed), pack_conv_weight_bf16x3(w_packed))
+        base = w_packed._base if w_packed._base is not None else w_packed
+        w3 = pack_conv_weight_bf16x3(w_packed)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(w3.device).synchronize()      # complete before another stream can hit the entry
+        hit = _W3_CACHE[key] = (base, w3)
     return hit[1]
 
 
 def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_logical=None, scale=None, shift=None,
                 residual=None, act=ACT_NONE, slope=0.0, segs=None, out=None, out_off=0, tile=0, split_k=0,
-                precision=0, x2=None, stride2=1, x2_off=0) -> torch.Tensor:
+                precision=0, x2=None, stride2=1, x2_off=0, w3=None) -> torch.Tensor:
     """Implicit-GEMM convolution on an NHWC tensor [N,H,W,P].  ``w_packed`` is [Cout,KH,KW,Cin]
     (see pack_conv_weight); ``kw_logical`` is the filter width before zero-tap padding (it fixes OW).
     ``segs`` = [(channel offset, length), ...] inside the P-wide pixel (default: the first Cin
     channels).  Returns / fills an NHWC output [N,OH,OW,Pout].
     ``x2`` [N,H2,W2,P2] is the optional second source of tsod_conv2d_dual_f32: ``w_packed`` is then [Cout, K1 + C2] with the
     last C2 columns contracting channels [x2_off, x2_off + C2) of pixel (oh*stride2, ow*stride2) of ``x2`` (``kernel`` =
-    (KH, KW, Cin) of the first source must be given through ``segs`` / a 1x1 filter: only 1x1 first sources here)."""
+    (KH, KW, Cin) of the first source must be given through ``segs`` / a 1x1 filter: only 1x1 first sources here).
+    ``w3``: the pre-split bf16x3 image of ``w_packed`` (pack_conv_weight_bf16x3) when the caller keeps one; used with
+    ``precision`` = bf16x3 instead of the wrapper's own cache."""
     require_cuda(x, "conv2d")
     assert x.is_contiguous() and w_packed.is_contiguous()
     N, H, W, P = x.shape
@@ -178,7 +189,8 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
                        precision=precision, src2=src2)
     ws_bytes = lib().tsod_conv2d_workspace_bytes(byref(d))
     ws = CONV_ARENA.get(x.device, ws_bytes) if ws_bytes else None
-    w_arg = _w3_for(w_packed) if precision == _ffi.PREC_BF16X3 else w_packed     # bf16x3 reads the pre-split weight image
+    # bf16x3 reads the pre-split weight image
+    w_arg = (w3 if w3 is not None else _w3_for(w_packed)) if precision == _ffi.PREC_BF16X3 else w_packed
     check(lib().tsod_conv2d_dual_f32(byref(d), ptr(x), ptr(x2), ptr(w_arg), ptr(scale), ptr(shift), ptr(residual), ptr(out),
                                      ptr(ws), ws_bytes, stream_ptr()), "conv2d")
     return out
@@ -325,6 +337,16 @@ def loc2bbox(src: torch.Tensor, loc: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(loc)
     if loc.shape[0]:
         check(lib().tsod_loc2bbox_f32(ptr(src), ptr(loc), loc.shape[0], ptr(out), stream_ptr()), "loc2bbox")
+    return out
+
+
+def bbox2loc(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """src [n,4], dst [n,4] xyxy -> offsets [n,4] (tsod_bbox2loc_f32; utils/loc_bbox_iou.py:63-88)."""
+    require_cuda(src, "bbox2loc")
+    src, dst = src.float().contiguous(), dst.to(src.device, torch.float32).contiguous()
+    out = torch.empty_like(src)
+    if src.shape[0]:
+        check(lib().tsod_bbox2loc_f32(ptr(src), ptr(dst), src.shape[0], ptr(out), stream_ptr()), "bbox2loc")
     return out
 
 

@@ -75,6 +75,16 @@ class HarNetRoIHead(PlanOwner, nn.Module):
             ent = self._packed_cache[("head", dev)] = (w.to(dev).contiguous(), b.to(dev), n_loc, n_sc)
         return ent
 
+    def _w3(self, dev):
+        """The pre-split bf16x3 image of the fused weight, made once and kept beside it (a constant of the forward: it must
+        not be re-split - and baked into a captured graph - on every call)."""
+        w3 = self._packed_cache.get(("head.w3", dev))
+        if w3 is None:
+            w3 = self._packed_cache[("head.w3", dev)] = hip_ops.pack_conv_weight_bf16x3(self._pack(dev)[0])
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(dev).synchronize()       # complete before another slot's stream uses it
+        return w3
+
     def forward_nhwc(self, feat, rois, roi_indices, img_size):
         """feat NHWC [n,Hf,Wf,C]; rois [n,R,4] image coords; roi_indices [n]; img_size (H,W) (quirk Q2)."""
         require_cuda(feat, "HarNetRoIHead")
@@ -94,7 +104,8 @@ class HarNetRoIHead(PlanOwner, nn.Module):
         M, K = fc7.shape
         tile, split, prec = self.__dict__.get("_gemm_choice", {}).get(M, (0, 0, 0))
         both = hip_ops.conv2d_nhwc(fc7.view(1, 1, M, K), w.view(w.shape[0], 1, 1, K), shift=b, tile=tile, split_k=split,
-                                   precision=prec).view(M, w.shape[0])             # [n*R, pad4(5*n_class)]
+                                   precision=prec, w3=self._w3(feat.device) if prec else None
+                                   ).view(M, w.shape[0])                           # [n*R, pad4(5*n_class)]
         # views into the fused output (row pitch 408 for 81 classes): same values and shapes as the reference's two
         # Linear outputs; .contiguous() them if a consumer needs dense storage
         return both[:, :n_loc].view(n, -1, n_loc), both[:, n_loc:n_loc + n_sc].view(n, -1, n_sc)
@@ -103,7 +114,8 @@ class HarNetRoIHead(PlanOwner, nn.Module):
         """Pin the fastest (tile, K-slice schedule, arithmetic) of the fused cls_loc + score GEMM for M = fc7.shape[0] RoIs."""
         w, b, _, _ = self._pack(fc7.device)
         M, K = fc7.shape
-        self.__dict__.setdefault("_gemm_choice", {})[M] = hip_ops.tune_conv(fc7.view(1, 1, M, K), w.view(w.shape[0], 1, 1, K), shift=b)
+        self.__dict__.setdefault("_gemm_choice", {})[M] = hip_ops.tune_conv(fc7.view(1, 1, M, K), w.view(w.shape[0], 1, 1, K), shift=b,
+                                                                             w3=self._w3(fc7.device))
         return self._gemm_choice[M]
 
     def forward(self, x, rois, roi_indices, img_size):

@@ -52,6 +52,13 @@ class FasterRCNN(nn.Module):
                                   in_channels=feat_ch, roi_op=roi_op)
         self.__dict__["_uid"] = next(_UID)          # scratch ownership: (this detector, slot), see hip_ops._Arena
 
+    def __setstate__(self, state):
+        """copy.deepcopy / unpickling: the copy is ANOTHER detector - it gets its own scratch-ownership id (sharing one would
+        make two detectors share K-slice slabs, arrival tickets and NMS scratch across streams) and no cached constants."""
+        super().__setstate__(state)
+        self.__dict__["_uid"] = next(_UID)
+        self.__dict__.pop("_roi_idx_cache", None)
+
     def weights_version(self):
         """Changes whenever packed weights were invalidated (load_state_dict / .to() / invalidate_packed)."""
         return (self.extractor.weights_version, self.rpn.weights_version, self.head.weights_version)
@@ -102,6 +109,21 @@ class FasterRCNN(nn.Module):
             n_post = self.rpn.proposal_layer.counts()[1]
             fc7 = torch.randn(x.shape[0] * n_post, self.head.cls_loc.in_features, device=x.device)
             return rpn_choice, self.head.autotune(fc7)
+
+    def head_choices(self):
+        """The pinned (tile, K-slice schedule, arithmetic) choices of the two GEMMs outside the backbone plan as plain data
+        (JSON-able): {"rpn": {"NxHxW": [tile, split_k, precision]}, "head": {"M": [...]}} - what ``autotune_heads`` found,
+        to be persisted beside the backbone's tile table or shipped to other ranks."""
+        rpn = {"x".join(str(v) for v in k): [int(c) for c in v] for k, v in self.rpn.__dict__.get("_gemm_choice", {}).items()}
+        head = {str(k): [int(c) for c in v] for k, v in self.head.__dict__.get("_gemm_choice", {}).items()}
+        return {"rpn": rpn, "head": head}
+
+    def set_head_choices(self, choices):
+        """Pin choices exported by ``head_choices`` (no tuning launches; every rank of a job then sums in the same order)."""
+        for k, v in (choices or {}).get("rpn", {}).items():
+            self.rpn.__dict__.setdefault("_gemm_choice", {})[tuple(int(t) for t in k.split("x"))] = tuple(int(c) for c in v)
+        for k, v in (choices or {}).get("head", {}).items():
+            self.head.__dict__.setdefault("_gemm_choice", {})[int(k)] = tuple(int(c) for c in v)
 
     def detections(self, x, scale=1.):
         """[B,R,6] rows (x1,y1,x2,y2, max logit, arg-max class): SURVEY D5 / frcnn_training.py:311-319."""

@@ -20,7 +20,7 @@ from torch import nn
 
 from .. import hip_ops
 from .._ffi import ACT_NONE, TsodError, require_cuda
-from ..engine import PackedConv, PlanOwner
+from ..engine import PackedConv, PlanOwner, weights_bf16x3
 from ..utils._config import load_config
 from ..utils.basic_anchors import generate_basic_anchor
 
@@ -118,7 +118,8 @@ class RegionProposalNetwork(PlanOwner, nn.Module):
         n, h, w, _ = feat.shape
         pc, base, n_loc, n_sc = self._pack(feat.device)
         tile, split, prec = self.__dict__.get("_gemm_choice", {}).get((n, h, w), (0, 0, 0))
-        fused = hip_ops.conv2d_nhwc(feat, pc.w, shift=pc.shift, tile=tile, split_k=split, precision=prec).view(n * h * w, pc.cout)
+        fused = hip_ops.conv2d_nhwc(feat, pc.w, shift=pc.shift, tile=tile, split_k=split, precision=prec,
+                                    w3=weights_bf16x3(pc) if prec else None).view(n * h * w, pc.cout)
         boxes, _, keys, anchor = hip_ops.rpn_decode(fused[:, :n_loc], fused[:, n_loc:n_loc + n_sc], base, n, h, w,
                                                     self.feat_stride, img_size[1], img_size[2],
                                                     self.proposal_layer.min_size * scale, want_anchors=want_anchors)
@@ -128,7 +129,7 @@ class RegionProposalNetwork(PlanOwner, nn.Module):
         """Pin the fastest (tile, K-slice schedule, arithmetic) of the fused loc + score GEMM for this feature geometry."""
         n, h, w, _ = feat.shape
         pc = self._pack(feat.device)[0]
-        self.__dict__.setdefault("_gemm_choice", {})[(n, h, w)] = hip_ops.tune_conv(feat, pc.w, shift=pc.shift)
+        self.__dict__.setdefault("_gemm_choice", {})[(n, h, w)] = hip_ops.tune_conv(feat, pc.w, shift=pc.shift, w3=weights_bf16x3(pc))
         return self._gemm_choice[(n, h, w)]
 
     def forward_nhwc(self, feat: torch.Tensor, img_size, scale=1.):

@@ -1,8 +1,8 @@
 """Box arithmetic with the reference's function surface (utils/loc_bbox_iou.py), on HIP kernels.
 
-Only the two functions on the inference path are provided: ``bbox_iou`` (reference :4-27) and
-``loc2bbox`` (:29-61).  ``bbox2loc`` / ``xywh2xyxy`` serve training targets and data loading and are
-out of this path's scope.
+``bbox_iou`` (reference :4-27) and ``loc2bbox`` (:29-61) are on the inference path; ``bbox2loc`` (:63-88) serves the
+training-side target creators and is the same device function they call.  ``xywh2xyxy`` (:91-97, a
+list helper of the data loader) is out of this path's scope.
 """
 from __future__ import annotations
 
@@ -28,3 +28,11 @@ def loc2bbox(src_bbox, loc):
         out = hip_ops.loc2bbox(src_bbox.repeat_interleave(k, dim=0), loc.reshape(-1, 4))
         return out.view(loc.shape[0], 4 * k)
     return hip_ops.loc2bbox(src_bbox, loc)
+
+
+def bbox2loc(src_bbox, dst_bbox):
+    """Offsets (dx,dy,dw,dh) that take ``src_bbox`` [n,4] to ``dst_bbox`` [n,4] (widths / heights floored at f32 eps):
+    ``loc2bbox(src, bbox2loc(src, dst)) == dst`` (the reference's own known answer, utils/loc_bbox_iou.py:103)."""
+    if src_bbox.shape[1] != 4 or dst_bbox.shape[1] != 4:
+        raise IndexError
+    return hip_ops.bbox2loc(src_bbox, dst_bbox)

@@ -5,13 +5,15 @@ path consumes costs host work per layer: eval-BN folding in f64, HarDNet's per-l
 packing, the fused RPN / head weight stacks.  The result depends only on the state_dict, so it is computed once and
 kept on disk:
 
-    <dir>/<backbone>-<sha256 of the state_dict, 32 hex>.tsodpack      torch.save of {"format", "backbone", "hash",
+    <dir>/<backbone>-<sha256 of state_dict + config, 32 hex>.tsodpack torch.save of {"format", "backbone", "hash",
                                                                      "entries": {owner: {layer key: packed state}}}
     <dir>/tiles-<backbone>-<N>x<H>x<W>-<device name>.json             autotuned (tile, split_k) table per input geometry
 
 The packed state of a layer is plain data (tensors, numbers, strings, lists): the file loads with ``weights_only=True``.
-Everything in it is keyed by the hash of the weights it was made from, so a stale file can never be applied to other
-weights; a file that does not match the model's layer set is ignored and rewritten.
+Everything in it is keyed by ONE hash over what the packed form depends on: the state_dict (keys, dtypes, shapes, bytes - so
+the layer set too) AND the inputs that are not in the state_dict (``config_fingerprint``: base anchors, feat_stride, RoI op,
+BatchNorm eps values, shortcut fusion, this file's FORMAT).  A stale file can therefore never be applied to other weights or to
+a detector with other anchors; a file whose format / backbone / owner names do not match is ignored and rewritten.
 """
 from __future__ import annotations
 
@@ -23,7 +25,7 @@ import torch
 
 from ._ffi import TsodError
 
-FORMAT = 2
+FORMAT = 3
 
 
 # ----------------------------------------------------------------------------- hashing
@@ -38,6 +40,19 @@ def state_dict_hash(sd) -> str:
         h.update(str(tuple(t.shape)).encode())
         h.update(t.reshape(-1).view(torch.uint8).numpy().tobytes() if t.numel() else b"")
     return h.hexdigest()[:32]
+
+
+def config_fingerprint(model) -> bytes:
+    """What the packed entries depend on besides the state_dict: the RPN entry stores the base anchors (ratios /
+    anchor_scales), the folded weights depend on every BatchNorm's eps, the plan on shortcut fusion and the RoI op."""
+    import numpy as np
+    h = hashlib.sha256()
+    h.update(f"format{FORMAT}|stride{model.feat_stride}|roi{model.head.roi_op}|fuse{int(bool(model.extractor.fuse_shortcut))}|".encode())
+    h.update(np.ascontiguousarray(np.asarray(model.rpn.anchor_base, dtype=np.float32)).tobytes())
+    for name, m in model.named_modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            h.update(f"{name}:{m.eps!r}:{int(m.affine)}|".encode())
+    return h.digest()
 
 
 # ----------------------------------------------------------------------------- (de)serialising packed objects
@@ -81,7 +96,8 @@ def _owners(model):
 
 # ----------------------------------------------------------------------------- public API
 def cache_path(directory, model) -> str:
-    return os.path.join(directory, f"{model.backbone}-{state_dict_hash(model.state_dict())}.tsodpack")
+    h = hashlib.sha256(state_dict_hash(model.state_dict()).encode() + config_fingerprint(model)).hexdigest()[:32]
+    return os.path.join(directory, f"{model.backbone}-{h}.tsodpack")
 
 
 def pack_all(model, device) -> None:
@@ -157,8 +173,10 @@ def tiles_path(directory, model, shape, device) -> str:
 def save_tiles(model, directory, shape, device, tiles) -> str:
     os.makedirs(directory, exist_ok=True)
     path = tiles_path(directory, model, shape, device)
-    with open(path, "w") as f:
+    tmp = path + f".tmp{os.getpid()}"
+    with open(tmp, "w") as f:
         json.dump([list(t) for t in tiles], f)
+    os.replace(tmp, path)                                   # atomic: ranks tuning concurrently share the <device name> path
     return path
 
 
