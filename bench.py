@@ -100,6 +100,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs behind roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dump-layers", default=None, help="write the serial plan's conv launches (name, FLOPs, algorithmic bytes, tile, "
+                    "K-slice slab bytes, HIP-event time) as JSON: the per-layer columns of scripts/summarize_pmc.py")
     ap.add_argument("--cpu-reps", type=int, default=8)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--check", action="store_true", default=None, help="N > 1: compare the gathered records with single-GPU forwards "
@@ -168,18 +170,37 @@ def cpu_baseline(sd, backbone, x_cpu, reps):
             "seconds_per_forward": med}
 
 
-def conv_algorithmic_bytes(plan):
-    """Input + output + weights (+ residual) of every conv launch, each counted once (f32)."""
-    tot = 0
-    for st in plan.conv_steps:
-        d = st.desc
-        cin = sum(d.seg_len[i] for i in range(d.n_seg))
-        tot += 4 * (d.N * d.H * d.W * cin + d.N * d.OH * d.OW * d.Cout + d.Cout * d.KH * d.KW * cin)
-        if d.c2 > 0:                                  # second source of a fused shortcut: the pixels it taps + its weights
-            tot += 4 * (d.N * d.OH * d.OW * d.c2 + d.Cout * d.c2)
-        if d.res_pitch > 0:
-            tot += 4 * d.N * d.OH * d.OW * d.Cout
+def step_algorithmic_bytes(st):
+    """Input + output + weights (+ residual, + second source) of one conv launch, each counted once (f32)."""
+    d = st.desc
+    cin = sum(d.seg_len[i] for i in range(d.n_seg))
+    tot = 4 * (d.N * d.H * d.W * cin + d.N * d.OH * d.OW * d.Cout + d.Cout * d.KH * d.KW * cin)
+    if d.c2 > 0:                                      # second source of a fused shortcut: the pixels it taps + its weights
+        tot += 4 * (d.N * d.OH * d.OW * d.c2 + d.Cout * d.c2)
+    if d.res_pitch > 0:
+        tot += 4 * d.N * d.OH * d.OW * d.Cout
     return tot
+
+
+def conv_algorithmic_bytes(plan):
+    return sum(step_algorithmic_bytes(st) for st in plan.conv_steps)
+
+
+def dump_layers(plan, path, conv_ms=None):
+    """Per conv launch of the plan, in launch order: what scripts/summarize_pmc.py needs to put names, algorithmic bytes and
+    K-slice slab bytes beside the per-dispatch counters."""
+    from ctypes import byref
+    from two_stage_object_detection_amd._ffi import TILE_NAMES, lib
+    rows = []
+    for i, st in enumerate(plan.conv_steps):
+        d = st.desc
+        ws = int(lib().tsod_conv2d_workspace_bytes(byref(d)))
+        rows.append({"name": st.name, "flops": int(st.flops), "algorithmic_bytes": int(step_algorithmic_bytes(st)),
+                     "tile": TILE_NAMES[int(d.tile)], "split_k": int(d.split_k), "precision": int(d.precision),
+                     "slab_bytes": max(0, ws - 256 * 1024) if ws else 0, "M": int(d.N * d.OH * d.OW), "Cout": int(d.Cout),
+                     "K": int(d.KH * d.KW * sum(d.seg_len[j] for j in range(d.n_seg)) + max(0, int(d.c2))),
+                     "event_us": None if conv_ms is None else round(conv_ms[i] * 1e3, 2)})
+    json.dump(rows, open(path, "w"), indent=0)
 
 
 def pmc_child(args, dev):
@@ -501,6 +522,8 @@ def main(argv=None):
         # ---- schedule 1: strictly serial (one graph, one stream) + the per-kernel roofline that belongs to it
         plan.import_tiles(tiles["serial"])
         conv_ms = conv_event_times(plan)
+        if args.dump_layers and rank == 0:
+            dump_layers(plan, args.dump_layers, conv_ms)
         conv_flops = sum(st.flops for st in plan.conv_steps)
         algo_bytes = conv_algorithmic_bytes(plan)
         precs = [int(st.desc.precision) for st in plan.conv_steps]

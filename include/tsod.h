@@ -76,7 +76,10 @@ enum { TSOD_TILE_AUTO = 0, TSOD_TILE_128x128 = 1, TSOD_TILE_128x64 = 2, TSOD_TIL
        /* bf16x3 only, fed by LDS-DMA (conv_dma_kernel): one channel segment, Cin a multiple of the K stage (16 / 32) */
        TSOD_TILE_D128x128 = 17, TSOD_TILE_D64x128 = 18, TSOD_TILE_D256x128 = 19,
        TSOD_TILE_D64x128_S2 = 20 /* two ring stages: two workgroups per CU */,
-       TSOD_TILE_D128x256 = 21 /* two columns of waves share the activation stage */, TSOD_TILE_COUNT = 22 };
+       TSOD_TILE_D128x256 = 21 /* two columns of waves share the activation stage */,
+       TSOD_TILE_D128x128_K32 = 22 /* 8 waves (4 along M x 2 along K), 32-float stages, 3-stage ring: two waves per SIMD at one
+                                      workgroup per CU - the small-M (batch-1) tile */,
+       TSOD_TILE_COUNT = 23 };
 /* arithmetic of the contraction.  F32: v_mfma_f32_32x32x2_f32 (a k-ordered f32 fma chain).  BF16X3: every f32 operand cut
  * exactly into three bf16 pieces (hi + mid + lo == x), six piece products per k accumulated in f32 on
  * v_mfma_f32_32x32x16_bf16: f32-level accuracy (error ~1.3e-7 of sum|a*b|) at 0.375x the matrix-pipe time; storage,

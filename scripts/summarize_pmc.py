@@ -32,11 +32,19 @@ def load(d):
     return per, dur
 
 
-label = sys.argv[1]
-sq, dsq = load(sys.argv[2]); fe, dfe = load(sys.argv[3]); wr, dwr = load(sys.argv[4])
-print(f"# {label} - PMC counters, `bench.py --no-graph --in-flight 1` (B=1, 3x800x1333, ResNet-50), rocprofv3 --pmc, separate passes\n")
-print("Per dispatch, averaged over the second half of each kernel's dispatches (the timed steps; the first half contains plan")
-print("building and autotune-free warm-up).  `FETCH_SIZE` / `WRITE_SIZE` are KiB; on gfx950 `FETCH_SIZE` under-reports wide")
+import argparse
+import json
+ap = argparse.ArgumentParser()
+ap.add_argument("label"); ap.add_argument("sq"); ap.add_argument("fetch"); ap.add_argument("write")
+ap.add_argument("--layers", default=None, help="bench.py --dump-layers JSON: adds the per-layer table of the last forward")
+ap.add_argument("--tcc", default=None, help="a fourth pass with TCC_HIT_sum TCC_MISS_sum (L2 hit rate per layer)")
+ap.add_argument("--workload", default="B=1, 3x800x1333, ResNet-50")
+A = ap.parse_args()
+label = A.label
+sq, dsq = load(A.sq); fe, dfe = load(A.fetch); wr, dwr = load(A.write)
+print(f"# {label} - PMC counters, `bench.py --no-graph --in-flight 1` ({A.workload}), rocprofv3 --pmc, separate passes\n")
+print("Per dispatch, averaged over the dispatches of the second half of the forwards (the timed steps; the first half contains plan")
+print("building and warm-up; kernels that only ran before that - tuning candidates - are not listed).  `FETCH_SIZE` / `WRITE_SIZE` are KiB; on gfx950 `FETCH_SIZE` under-reports wide")
 print("coalesced reads by 2x (MI355X_MICROARCH.md, HBM section), so HBM read bytes = 2 x FETCH_SIZE.  Commands: profiles/README.md.\n")
 g = [c.get('GRBM_GUI_ACTIVE') for k in fe if ('conv_igemm' in k or 'conv_dma' in k) for _, c in fe[k].items() if c.get('GRBM_GUI_ACTIVE')]
 d = [dfe[i] for k in fe if ('conv_igemm' in k or 'conv_dma' in k) for i, c in fe[k].items() if c.get('GRBM_GUI_ACTIVE')]
@@ -48,11 +56,28 @@ print("arithmetic: 0 / absent = f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16x3 (v
 print("| kernel | arithmetic | dispatches | avg us | MFMA busy | SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES | SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE |")
 print("|---|---|---:|---:|---:|---:|---:|")
 tot = collections.defaultdict(lambda: [0.0, 0.0])
+def forward_starts(per):
+    """dispatch ids of the layout kernel that opens every forward (eager bench: one per step)"""
+    return sorted(int(i) for k in per if 'nchw_to_nhwc' in k for i in per[k])
+
+
+def timed_only(per, items):
+    """keep the dispatches of the LAST HALF of the forwards: no plan building, no tuning candidates (with a tiles file that
+    carries the head choices there are none anyway)"""
+    st = forward_starts(per)
+    if not st:
+        return items[len(items) // 2:]
+    lo = st[len(st) // 2]
+    return [(i, c) for i, c in items if int(i) >= lo]
+
+
 for k in sorted(sq):
     if 'conv_igemm' not in k and 'conv_dma' not in k:
         continue
-    ds = list(sq[k].items()); ds = ds[len(ds) // 2:]
+    ds = timed_only(sq, list(sq[k].items()))
     n = len(ds)
+    if n == 0:
+        continue
     us = sum(dsq[i] for i, _ in ds) / n
     avg = lambda name: sum(c.get(name, 0) for _, c in ds) / n
     mf, wc, wi, bc, la = avg('SQ_VALU_MFMA_BUSY_CYCLES'), avg('SQ_WAVE_CYCLES'), avg('SQ_WAIT_INST_ANY'), avg('SQ_LDS_BANK_CONFLICT'), avg('SQ_LDS_IDX_ACTIVE')
@@ -107,3 +132,44 @@ if fam in lf:
     print("(a) the K-slice partial slabs (write-through stores, read back by the tile's last-arriving slice), (b) the activation")
     print("tile re-read by every output-channel tile of its row block once it has left the XCD's L2, (c) the 7x8x4 stem reading its")
     print("4-channel input 7 times, (d) for bf16x3 layers the pre-split weight image (6 instead of 4 bytes per weight).")
+
+
+def last_forward_convs(per, dur):
+    """[(dispatch id, kernel, counters, us)] of the conv GEMMs of the last forward, in launch order"""
+    st = forward_starts(per)
+    lo = st[-1]
+    rows = [(int(i), k, c, dur[i]) for k in per if ('conv_igemm' in k or 'conv_dma' in k) for i, c in per[k].items() if int(i) >= lo]
+    return sorted(rows)
+
+
+if A.layers:
+    layers = json.load(open(A.layers))
+    sqr, fer, wrr = last_forward_convs(sq, dsq), last_forward_convs(fe, dfe), last_forward_convs(wr, dwr)
+    tcr = None
+    if A.tcc:
+        tc, dtc = load(A.tcc)
+        tcr = last_forward_convs(tc, dtc)
+    print("\n## Per conv layer (last forward of every pass, launch order; names, algorithmic and slab bytes from `bench.py --dump-layers`)\n")
+    print("`HBM MB` = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / 1e6 of that dispatch; `slab MB` = the K-slice partial slabs of the chosen")
+    print("schedule, counted twice (written write-through by the slices, read back by the last arriver): the part of the excess that is the")
+    print("price of filling the chip by cutting K; `x alg` = HBM MB / algorithmic MB; `L2 hit` = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum).\n")
+    print("| # | layer | tile | split | us | MFMA busy | HBM MB | algorithmic MB | x alg | slab MB (w+r) | HBM - slab, x alg | L2 hit |")
+    print("|---:|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
+    tot = [0.0, 0.0, 0.0, 0.0]
+    for j, L in enumerate(layers):
+        if j >= len(sqr) or j >= len(fer) or j >= len(wrr):
+            break
+        us = sqr[j][3]
+        mf = sqr[j][2].get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (4 * 256 * us * 1e-6 * clock)
+        mb = (2 * fer[j][2].get('FETCH_SIZE', 0) + wrr[j][2].get('WRITE_SIZE', 0)) * 1024 / 1e6
+        alg_mb, slab = L['algorithmic_bytes'] / 1e6, 2 * L['slab_bytes'] / 1e6
+        # the workspace is sized for every slab the schedule COULD use; balanced / hybrid schedules touch all of them
+        hit = ''
+        if tcr is not None and j < len(tcr):
+            h, m = tcr[j][2].get('TCC_HIT_sum', 0), tcr[j][2].get('TCC_MISS_sum', 0)
+            hit = f"{100 * h / max(1, h + m):.0f}%"
+        tot[0] += us; tot[1] += mb; tot[2] += alg_mb; tot[3] += slab
+        print(f"| {j} | {L['name']} | {L['tile']} | {L['split_k']} | {us:.1f} | {100 * mf:.1f}% | {mb:.1f} | {alg_mb:.1f} | {mb / alg_mb:.2f} | "
+              f"{slab:.1f} | {(mb - slab) / alg_mb:.2f} | {hit} |")
+    print(f"| | **all {len(layers)} trunk convs** | | | {tot[0]:.0f} | | {tot[1]:.0f} | {tot[2]:.0f} | {tot[1] / tot[2]:.2f} | {tot[3]:.0f} | "
+          f"{(tot[1] - tot[3]) / tot[2]:.2f} | |")

@@ -100,8 +100,8 @@ def test_trainer_checkpoint_to_hip_forward_with_packed_cache(dev, tmp_path, back
         assert weight_cache.cache_path(str(cache), m3) != weight_cache.cache_path(str(cache), m1)
         assert m3.use_packed_cache(str(cache)) == "miss"
         base3 = m3.rpn._pack(dev)[1].cpu()
-        assert torch.equal(base3, torch.as_tensor(m3.rpn.anchor_base, dtype=torch.float32))
-        assert not torch.equal(base3, torch.as_tensor(m1.rpn.anchor_base, dtype=torch.float32))
+        assert torch.equal(base3, torch.as_tensor(m3.rpn.anchor_base, dtype=torch.float32).cpu())
+        assert not torch.equal(base3, torch.as_tensor(m1.rpn.anchor_base, dtype=torch.float32).cpu())
 
     # tile tables ride along, keyed by geometry + device
     plan = m1.extractor._plan_for(x.to(dev))

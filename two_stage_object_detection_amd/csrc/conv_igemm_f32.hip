@@ -148,7 +148,8 @@ struct SliceMap {
     }
 };
 
-template <int BM, int BN, int WM, int WN, int THREADS>
+// G = slabs of OTHER slices a combining thread keeps in flight at once (registers: G * 32 on top of the running sums)
+template <int BM, int BN, int WM, int WN, int THREADS, int G = 1>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[WM / 32][WN / 32], float *smem, int tid, int wm, int wn,
                                               int m0, int n0, const SliceMap sm) {
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -253,22 +254,39 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
                 qoff[u] = (unsigned)q * 16u;
                 mq[u] = m0 + q / QPR;
                 nq[u] = n0 + (q % QPR) * 4;
-                v[u] = buffer_load4_aux<AUX_SC1>(rs_part, sm.slab(0) * slab_bytes + qoff[u]);
             }
-            if (p.vec_epilogue) {                                          // the residual rides along with the first slice
+            if (p.vec_epilogue) {                                          // the residual rides along with the first group of slices
 #pragma unroll
                 for (int u = 0; u < QB; ++u) {
                     const bool ok = mq[u] < p.M && nq[u] < p.Cout && p.res != nullptr;
                     rs4[u] = buffer_load4(rs_r, ok ? ((unsigned)mq[u] * (unsigned)p.res_pitch + (unsigned)(p.res_off + nq[u])) * 4u : kOOB);
                 }
             }
-            for (int sl = 1; sl < sm.count; ++sl) {
-                float4 t[QB];
-                const unsigned so = sm.slab(sl) * slab_bytes;
+            // G slices' loads in flight together (one round trip beyond the XCD per group of G, the first group included, not one
+            // per slice); the adds stay in slice order: v = slab 0, then + slab 1, + slab 2, ...  The group-size tests are
+            // wave-uniform (sm.count is a property of the tile).
+            for (int sl = 0; sl < sm.count; sl += G) {
+                float4 t[G][QB];
 #pragma unroll
-                for (int u = 0; u < QB; ++u) t[u] = buffer_load4_aux<AUX_SC1>(rs_part, so + qoff[u]);
+                for (int gi = 0; gi < G; ++gi) {
+                    if (sl + gi < sm.count) {
+                        const unsigned so = sm.slab(sl + gi) * slab_bytes;
 #pragma unroll
-                for (int u = 0; u < QB; ++u) { v[u].x += t[u].x; v[u].y += t[u].y; v[u].z += t[u].z; v[u].w += t[u].w; }
+                        for (int u = 0; u < QB; ++u) t[gi][u] = buffer_load4_aux<AUX_SC1>(rs_part, so + qoff[u]);
+                    }
+                }
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) {
+                    if (sl + gi < sm.count) {
+                        if (gi == 0 && sl == 0) {
+#pragma unroll
+                            for (int u = 0; u < QB; ++u) v[u] = t[0][u];
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < QB; ++u) { v[u].x += t[gi][u].x; v[u].y += t[gi][u].y; v[u].z += t[gi][u].z; v[u].w += t[gi][u].w; }
+                        }
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < QB; ++u) {
@@ -309,6 +327,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
         // column-per-lane form.  Only LDS ops of this wave touch the patch: in-order LDS + lgkmcnt(0) orders them.
         float *patch = smem + wave * (32 * kPatchLD);
         const int pr = lane >> 3, pc = (lane & 7) * 4;
+        // ALL residual loads of the wave's tile go out before the first transpose (one memory round trip for the tile, under
+        // the LDS work, instead of one per 32x32 block); no residual (wave-uniform): no loads at all
+        float4 rs_all[TN][TM][4];
+        if (has_res) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 32 + pc;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int m = m0 + wm * WM + i * 32 + pr + 8 * t;
+                        rs_all[j][i][t] = buffer_load4(rs_res, (m < p.M && n < p.Cout) ? ((unsigned)m * (unsigned)p.res_pitch + (unsigned)(p.res_off + n)) * 4u : kOOB);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) rs_all[j][i][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WN + j * 32 + pc;           // this lane's 4 output channels
@@ -321,14 +362,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + row_in) * kPatchLD + col_in] = acc[i][j][e];
                 const int mb = m0 + wm * WM + i * 32 + pr;
-                float4 rs[4], v[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int m = mb + 8 * t;
-                    const unsigned off = (m < p.M && n_ok && has_res)
-                                             ? ((unsigned)m * (unsigned)p.res_pitch + (unsigned)(p.res_off + n)) * 4u : kOOB;
-                    rs[t] = buffer_load4(rs_res, off);
-                }
+                float4 v[4];
+                const float4 (&rs)[4] = rs_all[j][i];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const float4 *>(patch + (pr + 8 * t) * kPatchLD + pc);
@@ -391,6 +426,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 // s_memrealtime (100 MHz) around its K loop; clock = d(memtime) / d(memrealtime) * 100 MHz (scripts/conv_clock.py).
 // The stamps go to a buffer of their own and nothing is computed from them.
 __device__ long long *g_clock_buf = nullptr;
+// conv_dma_kernel timeline (scripts/dma_timeline.py): 8 int64 per workgroup =
+//   [0] s_memrealtime at entry  [1] s_memrealtime at exit  [2] cycles in prologues (ring fill -> stage 0 visible)
+//   [3] cycles in K loops       [4] cycles in epilogues (incl. slab store, ticket, combine)  [5] K-steps  [6] segments  [7] XCC id
+__device__ long long *g_dma_stamps = nullptr;
 #endif
 
 template <int BM, int BN, int WM, int WN, int MIN_WAVES, int NBUF = 2, int BK = 32, int PREC = 0>
@@ -886,6 +925,11 @@ conv_dma_kernel(const ConvParams p) {
     // (BALANCED is a template argument: the loop over segments keeps enough scalar state alive to push the K loop's own
     //  scalars out of the SGPR file - the uniform-schedule instantiation has no such loop)
     constexpr bool balanced = BALANCED;
+#ifdef TSOD_CLOCK_DIAG
+    long long dg_rt0 = 0, dg_pro = 0, dg_loop = 0, dg_epi = 0, dg_c = 0, dg_steps = 0, dg_segs = 0;
+    const bool dg_on = g_dma_stamps != nullptr && tid == 0 && blockIdx.x < 8192;
+    if (dg_on) dg_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     long g = 0, g_end = 1;
     if (balanced) {
         g = (long)blockIdx.x * p.sk_q;
@@ -1092,6 +1136,9 @@ conv_dma_kernel(const ConvParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
+#ifdef TSOD_CLOCK_DIAG
+    if (dg_on) { dg_c = __builtin_amdgcn_s_memtime(); dg_steps += nk; ++dg_segs; }
+#endif
     if (nk > 0) {
         // prologue: every ring slot filled (stages kt_begin .. kt_begin + S - 1), stage 0 visible, its fragments in X
 #pragma unroll
@@ -1102,6 +1149,9 @@ conv_dma_kernel(const ConvParams p) {
         }
         wait_vm<(S - 1) * P>();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef TSOD_CLOCK_DIAG
+        if (dg_on) { const long long c = __builtin_amdgcn_s_memtime(); dg_pro += c - dg_c; dg_c = c; }
+#endif
         Frags X, Y;
         {
             const float4 raw0 = *reinterpret_cast<const float4 *>(lds + (a_addr[0] - lds0));
@@ -1146,6 +1196,9 @@ conv_dma_kernel(const ConvParams p) {
     }
 #undef TSOD_DMA
     __syncthreads();                                             // no wave reads the ring any more: the epilogue may use it
+#ifdef TSOD_CLOCK_DIAG
+    if (dg_on) { const long long c = __builtin_amdgcn_s_memtime(); dg_loop += c - dg_c; dg_c = c; }
+#endif
     float *smem = reinterpret_cast<float *>(lds);
     // The epilogue reads its parameters from the kernel-argument segment (the struct is the only argument) instead of from
     // `p`: values that only the epilogue needs then do not occupy scalar registers across the K loop (under the balanced
@@ -1180,11 +1233,24 @@ conv_dma_kernel(const ConvParams p) {
                 for (int e = 0; e < 16; ++e) acc2[0][b][e] = smem[((partner * 2 + b) * 16 + e) * 64 + lane] + acc[0][2 + b][e];
         }
         __syncthreads();
-        conv_epilogue<BM, BN, 32, 64, THREADS>(pe, acc2, smem, tid, wm, wk, m0, n0, sm);
+        conv_epilogue<BM, BN, 32, 64, THREADS, 3>(pe, acc2, smem, tid, wm, wk, m0, n0, sm);
     } else {
-        conv_epilogue<BM, BN, 32, 128, THREADS>(pe, acc, smem, tid, wm, wn, m0, n0, sm);
+        conv_epilogue<BM, BN, 32, 128, THREADS, 3>(pe, acc, smem, tid, wm, wn, m0, n0, sm);
     }
+#ifdef TSOD_CLOCK_DIAG
+    if (dg_on) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (diag only: the epilogue's stores have left)
+        dg_epi += __builtin_amdgcn_s_memtime() - dg_c;
+    }
+#endif
   }
+#ifdef TSOD_CLOCK_DIAG
+    if (dg_on) {
+        long long *o = g_dma_stamps + 8 * (long)blockIdx.x;
+        o[0] = dg_rt0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = dg_pro; o[3] = dg_loop; o[4] = dg_epi; o[5] = dg_steps; o[6] = dg_segs;
+        o[7] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID (id 20), bits [3:0]
+    }
+#endif
 }
 
 // torch [Cout][Cin_src][KH][KW_src] -> [Cout][KH][KW][Cin], zero-filling the added channels / taps
@@ -1239,7 +1305,7 @@ const TileInfo kTiles[TSOD_TILE_COUNT] = {
     {64, 64, 64, 8, 1.40f, 32, 1, 0},   {128, 64, 128, 4, 1.35f, 32, 1, 0}, {128, 64, 256, 4, 1.12f, 32, 1, 1}, {64, 128, 256, 4, 1.12f, 32, 1, 1},
     {128, 128, 256, 2, 1.02f, 32, 1, 1},
     {128, 128, 256, 2, 0.80f, 16, 4, 1, 1}, {64, 128, 256, 1, 0.95f, 32, 3, 1, 1}, {256, 128, 512, 1, 0.72f, 16, 4, 1, 1},
-    {64, 128, 256, 2, 0.98f, 32, 2, 1, 1}, {128, 256, 512, 1, 0.74f, 16, 4, 1, 1}};
+    {64, 128, 256, 2, 0.98f, 32, 2, 1, 1}, {128, 256, 512, 1, 0.74f, 16, 4, 1, 1}, {128, 128, 512, 1, 0.70f, 32, 3, 1, 1}};
 // bf16x3 = 1: the tile also exists as a bf16x3 variant (three bf16 planes per operand fit the 64 KB of static LDS)
 
 // workgroups per CU: the f32 figure (VGPR / LDS bound), for bf16x3 additionally capped by its larger LDS footprint
@@ -1550,6 +1616,7 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
             case TSOD_TILE_D256x128: launch_dma_tile<256, 16, 1, 4>(p, sc.grid, s); break;
             case TSOD_TILE_D64x128_S2: launch_dma_tile<64, 32, 2, 2>(p, sc.grid, s); break;
             case TSOD_TILE_D128x256: launch_dma_tile<128, 16, 1, 4, 2>(p, sc.grid, s); break;
+            case TSOD_TILE_D128x128_K32: launch_dma_tile<128, 32, 2, 3>(p, sc.grid, s); break;
             default: launch_tile<64, 64, 32, 32, 2, 2, 32, 1>(p, sc.grid, s); break;      // TSOD_TILE_64x64 (two LDS stages)
         }
         return tsod_launch_status();
@@ -1625,5 +1692,8 @@ extern "C" int tsod_pack_conv_weight_bf16x3(const float *w_packed, int32_t Cout,
 #ifdef TSOD_CLOCK_DIAG
 extern "C" int tsod_debug_set_clock_buf(long long *buf /* device, 2 * 32768 int64, or NULL */) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_clock_buf), &buf, sizeof(buf)) == hipSuccess ? TSOD_OK : TSOD_ERR_LAUNCH;
+}
+extern "C" int tsod_debug_set_dma_stamps(long long *buf /* device, 8 * 8192 int64, or NULL */) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_dma_stamps), &buf, sizeof(buf)) == hipSuccess ? TSOD_OK : TSOD_ERR_LAUNCH;
 }
 #endif

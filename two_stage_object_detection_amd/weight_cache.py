@@ -48,7 +48,9 @@ def config_fingerprint(model) -> bytes:
     import numpy as np
     h = hashlib.sha256()
     h.update(f"format{FORMAT}|stride{model.feat_stride}|roi{model.head.roi_op}|fuse{int(bool(model.extractor.fuse_shortcut))}|".encode())
-    h.update(np.ascontiguousarray(np.asarray(model.rpn.anchor_base, dtype=np.float32)).tobytes())
+    base = model.rpn.anchor_base
+    base = base.detach().cpu().numpy() if isinstance(base, torch.Tensor) else np.asarray(base)
+    h.update(np.ascontiguousarray(base.astype(np.float32)).tobytes())
     for name, m in model.named_modules():
         if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
             h.update(f"{name}:{m.eps!r}:{int(m.affine)}|".encode())
