@@ -237,11 +237,20 @@ int tsod_bbox2loc_f32(const float *src, const float *dst, int64_t n, float *out,
  *   idx[b][k]      = source index of the k-th best, k < n_sel; -1 beyond    (int32, [B][n_pre])
  *   boxes_out[b][k]= boxes[b][idx] (zeros beyond n_sel)                     ([B][n_pre][4]) (may be NULL)
  *   keys_out[b][k] = keys[b][idx]  (-inf beyond n_sel)                      ([B][n_pre])    (may be NULL)
- * n_pre <= 16384.  One workgroup per image, LDS radix-select + bitonic sort; rows of up to 81920 keys are held in
- * registers after one pass over memory, longer rows are re-read per pass. */
+ * n_pre <= 16384.  Small problems (B * n^2 <= 3e8): one launch that ranks every key against every key of its image on the
+ * whole chip.  Larger: one workgroup per image, LDS radix-select (rows of up to 81920 keys are held in registers after one
+ * pass over memory, longer rows are re-read per pass), then a bitonic sort there - or, with scratch (the _ws_ form below),
+ * the rank kernel over the selection. */
 int tsod_sort_topk_desc_f32(const float *keys, const float *boxes, int32_t B, int32_t n, int32_t n_pre,
                             int32_t *counts, int32_t *idx, float *boxes_out, float *keys_out,
                             tsod_stream_t stream);
+/* The same with caller-owned scratch (tsod_sort_topk_workspace_bytes; may be 0): the order of the selection is then
+ * computed by RANK on the whole chip (every key counts the keys before it: the composite keys (score, index) are
+ * distinct) instead of by a sorting network inside one workgroup per image.  Results are identical. */
+size_t tsod_sort_topk_workspace_bytes(int32_t B, int32_t n, int32_t n_pre);
+int tsod_sort_topk_desc_ws_f32(const float *keys, const float *boxes, int32_t B, int32_t n, int32_t n_pre,
+                               int32_t *counts, int32_t *idx, float *boxes_out, float *keys_out, void *workspace,
+                               size_t workspace_bytes, tsod_stream_t stream);
 
 /* Batched greedy NMS on boxes already sorted by descending score + the pad/truncate tail.
  * Replaces torchvision.ops.nms (nets/rpn.py:63) and nets/rpn.py:65-69.

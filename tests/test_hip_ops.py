@@ -319,6 +319,39 @@ def test_sort_topk_exact(ops, dev, B, n, n_pre):
         assert torch.equal(ks[b, :c].cpu(), keys[b][ref])
 
 
+@pytest.mark.parametrize("B,n,n_pre", [(2, 37800, 3000), (1, 9450, 3000), (4, 9450, 3000), (1, 40, 300)])
+def test_sort_topk_rank_paths_agree_with_the_network(ops, dev, B, n, n_pre):
+    """Three ways to the same order: the full rank sort (small B*n^2), select + rank on the chip (scratch given), select +
+    bitonic network in one workgroup (no scratch: tsod_sort_topk_desc_f32).  Heavy ties, +0 / -0, everything-equal rows and
+    rows shorter than n_pre: index work, so all outputs must be identical, neutral rows included."""
+    from two_stage_object_detection_amd import _ffi
+    g = torch.Generator().manual_seed(17)
+    keys = (torch.rand(B, n, generator=g) * 64).round() / 64
+    keys[torch.rand(B, n, generator=g) < 0.2] = float("-inf")
+    keys[0, ::7] = 0.0
+    keys[0, 3::7] = -0.0                                # ties with +0 (torch compares them equal): lower index first
+    if B > 1:
+        keys[1] = 0.25                                  # one huge tie group straddling the cut
+    boxes = torch.randn(B, n, 4, generator=g)
+    kd, bd = keys.to(dev), boxes.to(dev)
+    got = ops.sort_topk_desc(kd, bd, n_pre)             # wrapper: brings scratch when the library asks for it
+    L = _ffi.lib()
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    idx = torch.empty((B, n_pre), dtype=torch.int32, device=dev)
+    bs = torch.empty((B, n_pre, 4), device=dev)
+    ks = torch.empty((B, n_pre), device=dev)
+    _ffi.check(L.tsod_sort_topk_desc_f32(_ffi.ptr(kd), _ffi.ptr(bd), B, n, n_pre, _ffi.ptr(counts), _ffi.ptr(idx), _ffi.ptr(bs),
+                                         _ffi.ptr(ks), _ffi.stream_ptr()))
+    for a, b_ in zip(got, (counts, idx, bs, ks)):
+        assert torch.equal(a, b_)
+    for b in range(B):                                  # and both equal torch's stable sort of the finite keys
+        valid = torch.nonzero(torch.isfinite(keys[b])).squeeze(1)
+        ref = valid[torch.sort(keys[b][valid], descending=True, stable=True).indices[:n_pre]]
+        c = int(counts[b])
+        assert c == ref.numel() and torch.equal(idx[b, :c].cpu().long(), ref)
+        assert (idx[b, c:] == -1).all() and (bs[b, c:] == 0).all() and torch.isinf(ks[b, c:]).all() and (ks[b, c:] < 0).all()
+
+
 def test_sort_topk_all_filtered(ops, dev):
     keys = torch.full((2, 100), float("-inf"))
     keys[1, 7] = 0.5

@@ -79,6 +79,9 @@ _SIGNATURES = {
     "tsod_bbox2loc_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "tsod_sort_topk_desc_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p]),
+    "tsod_sort_topk_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "tsod_sort_topk_desc_ws_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_size_t, c_void_p]),
     "tsod_nms_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "tsod_nms_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -78,6 +78,7 @@ ARENA = _Arena()
 # zero when a launch starts and every launch leaves them zero, so these buffers are zero-filled once at allocation and
 # never lent to any other kernel (the NMS masks live in ARENA).
 CONV_ARENA = _Arena(zero=True)
+TOPK_ARENA = _Arena()           # the selection handed from the top-k's select pass to its rank pass
 
 
 # ----------------------------------------------------------------------------- layout
@@ -360,8 +361,10 @@ def sort_topk_desc(keys: torch.Tensor, boxes: torch.Tensor | None, n_pre: int):
     idx = torch.empty((B, n_pre), dtype=torch.int32, device=dev)
     bs = torch.empty((B, n_pre, 4), dtype=torch.float32, device=dev) if boxes is not None else None
     ks = torch.empty((B, n_pre), dtype=torch.float32, device=dev)
-    check(lib().tsod_sort_topk_desc_f32(ptr(keys), ptr(boxes), B, n, n_pre, ptr(counts), ptr(idx), ptr(bs), ptr(ks),
-                                        stream_ptr()), "sort_topk")
+    ws_bytes = lib().tsod_sort_topk_workspace_bytes(B, n, n_pre)
+    ws = TOPK_ARENA.get(dev, ws_bytes) if ws_bytes else None          # its own arena: the NMS mask of the same step lives in ARENA
+    check(lib().tsod_sort_topk_desc_ws_f32(ptr(keys), ptr(boxes), B, n, n_pre, ptr(counts), ptr(idx), ptr(bs), ptr(ks),
+                                           ptr(ws), ws_bytes, stream_ptr()), "sort_topk")
     return counts, idx, bs, ks
 
 
@@ -492,7 +495,10 @@ def filter_detections(det: torch.Tensor, iou_thr: float = 0.1, score_thresh: flo
     check(L.tsod_detection_keys_f32(ptr(det), B * R, thr, int(background_class), ptr(keys), stream_ptr()), "detection_keys")
     counts = torch.empty((B,), dtype=torch.int32, device=dev)
     idx = torch.empty((B, R), dtype=torch.int32, device=dev)
-    check(L.tsod_sort_topk_desc_f32(ptr(keys), None, B, R, R, ptr(counts), ptr(idx), None, None, stream_ptr()), "sort_topk")
+    ws_bytes = L.tsod_sort_topk_workspace_bytes(B, R, R)
+    ws_sort = TOPK_ARENA.get(dev, ws_bytes) if ws_bytes else None
+    check(L.tsod_sort_topk_desc_ws_f32(ptr(keys), None, B, R, R, ptr(counts), ptr(idx), None, None, ptr(ws_sort), ws_bytes,
+                                       stream_ptr()), "sort_topk")
     det_sorted = torch.empty_like(det)
     check(L.tsod_gather_rows_f32(ptr(det), ptr(idx), B, R, R, 6, ptr(det_sorted), stream_ptr()), "gather_rows")
     keep = torch.empty((B, R), dtype=torch.int32, device=dev)
