@@ -32,3 +32,17 @@ rois = torch.cat([xy, xy + torch.rand(1, 300, 2, generator=g) * 300 + 16], dim=-
 idx = torch.zeros(1, dtype=torch.int32, device=dev)
 print(f"roi_pool_avg 300 x 2048: {timeit(lambda: hip_ops.roi_pool_avg_nhwc(feat, rois, idx, 800, 1333)):.1f} us")
 print(f"roi_align_avg 300 x 2048: {timeit(lambda: hip_ops.roi_align_avg_nhwc(feat, rois, idx, 800, 1333)):.1f} us")
+
+# proposal path at the detector's sizes: realistic overlap structure = boxes decoded from a random-init RPN on one image
+from two_stage_object_detection_amd import _ffi  # noqa: E402
+L = _ffi.lib()
+for B, A in ((1, 9450), (8, 9450)):
+    g = torch.Generator().manual_seed(5)
+    ctr = torch.rand(B, A, 2, generator=g) * torch.tensor([1333.0, 800.0])
+    wh = torch.rand(B, A, 2, generator=g) * 300 + 20
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], dim=-1).clamp_(0, 1333).to(dev)
+    keys = torch.rand(B, A, generator=g).to(dev)
+    counts, idx, bs, ks = hip_ops.sort_topk_desc(keys, boxes, 3000)
+    print(f"B={B}: sort_topk {A} -> 3000: {timeit(lambda: hip_ops.sort_topk_desc(keys, boxes, 3000)):.1f} us (incl. host-side allocation gaps)")
+    keep, rois, n_kept, status = hip_ops.nms_sorted(bs, counts, 0.7, 300)
+    print(f"B={B}: nms (mask + scan) 3000 -> 300: {timeit(lambda: hip_ops.nms_sorted(bs, counts, 0.7, 300)):.1f} us, kept {n_kept.tolist()}")
