@@ -36,6 +36,7 @@
 // chain's is 1.4-2.5e-7).  Storage, accumulation, epilogue, scheduling and K-slice combine are unchanged.
 #include "tsod_internal.h"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -61,6 +62,9 @@ struct ConvParams {
     // `split` K-slices, one workgroup per (tile, slice), partial sums reduced by conv_reduce_kernel
     int dp_tiles, split, ksteps_per_split;
     int sk_q;                     // > 0: balanced schedule (conv_dma_kernel): K-steps per workgroup of the tile-major K-step sequence
+    int nmajor;                   // 1: workgroups of one XCD share an output-channel tile (and K-slice): the weights it streams
+                                  //    stay in that XCD's L2 and are fetched from beyond it once, not once per XCD (small-M layers,
+                                  //    where the weights outweigh the activations); 0: they share activation rows (the default)
     unsigned out_bytes, res_bytes;
     unsigned in_bytes, w_bytes;   // buffer-descriptor extents (hardware bounds check: out of range reads 0)
     int vec_epilogue;             // 1: channels/pitches/offsets are multiples of 4 -> dwordx4 epilogue
@@ -126,6 +130,38 @@ __device__ __forceinline__ int seg_channel(const ConvParams &p, int ci) {
     int ch = p.seg_off[0] + ci;
     for (int s = 1; s < p.n_seg; ++s) ch = ci >= p.seg_end[s - 1] ? p.seg_off[s] + (ci - p.seg_end[s - 1]) : ch;
     return ch;
+}
+
+// ---- workgroup -> (tile, K-slice) under the uniform schedules.  Blocks b, b + 8, ... share an XCD (private L2; observed
+// round-robin placement - a speed matter only, nothing here depends on it for correctness), so the launch's work items are put
+// in an order in which neighbours share operands and every XCD takes one CONTIGUOUS run of that order.
+//   default: whole tiles first, output-channel tile fastest - an XCD's run shares activation rows; the K-sliced left-over tiles
+//            keep the plain round-robin placement (dispatched last, spread over all XCDs);
+//   nmajor : (pure schedules only: every tile whole, or every tile cut into `split` slices) order = (output-channel tile,
+//            K-slice, row tile) with the row tile fastest - an XCD's run shares ONE block of the weights.
+// tile_id = row tile * tiles_n + output-channel tile (the ticket / slab index of a K-sliced tile is tile_id - dp_tiles).
+__device__ __forceinline__ void work_item(const ConvParams &p, int &tile_id, int &z) {
+    const int b = (int)blockIdx.x;
+    if (p.nmajor) {
+        const int nwg = (int)gridDim.x;
+        const int q = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+        const int L = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+        const int tm = L % p.tiles_m, rest = L / p.tiles_m;
+        const int split = p.dp_tiles > 0 ? 1 : p.split;
+        z = p.dp_tiles > 0 ? -1 : rest % split;
+        tile_id = tm * p.tiles_n + rest / split;
+        return;
+    }
+    if (b < p.dp_tiles) {
+        const int nwg = p.dp_tiles;
+        const int q = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+        tile_id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+        z = -1;
+    } else {
+        const int r = b - p.dp_tiles;
+        tile_id = p.dp_tiles + r / p.split;
+        z = r % p.split;
+    }
 }
 
 // ---- epilogue of one BM x BN tile held as 32x32 accumulator blocks, shared by every conv kernel of this file.
@@ -472,16 +508,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     // L2; blocks b, b+8, ... share one) walks a contiguous run of tiles sharing activation rows.  K-slice
     // workgroups keep the round-robin placement: they are dispatched last and spread over all XCDs.
     int tile_id, z;
-    if ((int)blockIdx.x < p.dp_tiles) {
-        const int nwg = p.dp_tiles;
-        const int q = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
-        tile_id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (blockIdx.x >> 3);
-        z = -1;
-    } else {
-        const int r = blockIdx.x - p.dp_tiles;
-        tile_id = p.dp_tiles + r / p.split;
-        z = r % p.split;
-    }
+    work_item(p, tile_id, z);
     const int tn_i = tile_id % p.tiles_n;
     const int tm_i = tile_id / p.tiles_n;
     const int m0 = tm_i * BM, n0 = tn_i * BN;
@@ -948,16 +975,7 @@ conv_dma_kernel(const ConvParams p) {
         g += kt_end - kt_begin;
     } else {
         int z;
-        if ((int)blockIdx.x < p.dp_tiles) {
-            const int nwg = p.dp_tiles;
-            const int q = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
-            tile_id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (blockIdx.x >> 3);
-            z = -1;
-        } else {
-            const int r = blockIdx.x - p.dp_tiles;
-            tile_id = p.dp_tiles + r / p.split;
-            z = r % p.split;
-        }
+        work_item(p, tile_id, z);
         kt_begin = z < 0 ? 0 : z * p.ksteps_per_split;
         kt_end = z < 0 ? p.ksteps : min(p.ksteps, kt_begin + p.ksteps_per_split);
         sm = {z, p.split, tile_id - p.dp_tiles, -1, 0, 0};
@@ -1371,6 +1389,15 @@ bool tile_ok_for(const tsod_conv2d_desc *d, int tile) {
     return desc_cin(d) % bk == 0 && (d->KH * d->KW * desc_cin(d)) % bk == 0 && d->c2 % bk == 0;
 }
 
+// TSOD_XCD_NMAJOR = 0 / 1 pins the XCD run order of the uniform schedules for experiments (unset: the byte estimate decides)
+int xcd_map_override() {
+    static const int v = [] {
+        const char *e = getenv("TSOD_XCD_NMAJOR");
+        return e == nullptr || *e == 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
+    }();
+    return v;
+}
+
 int g_cu_count = 0;
 int cu_count() {
     if (g_cu_count == 0) {
@@ -1391,6 +1418,7 @@ constexpr size_t kTicketBytes = 256 * 1024;   // tickets for up to 65536 K-slice
 struct Sched {
     int tile, bm, bn, tiles_m, tiles_n, tiles, dp_tiles, rem_tiles, split, ksteps_per_split, grid;
     int sk_q;                     // balanced schedule: K-steps per workgroup (0: a uniform schedule)
+    int nmajor;                   // XCD runs share an output-channel tile instead of activation rows (work_item)
     size_t ws_bytes, ticket_bytes;
     double cost;
 };
@@ -1411,6 +1439,7 @@ Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
     s.tiles = s.tiles_m * s.tiles_n;
     const int slots = cu_count() * residency(tile, d->precision);
     s.sk_q = 0;
+    s.nmajor = 0;
     if (mode == -2) {
         const int64_t total = (int64_t)s.tiles * ksteps;
         int64_t q = tsod_cdiv(total, slots);
@@ -1451,6 +1480,17 @@ Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
     }
     s.split = split; s.ksteps_per_split = kps; s.dp_tiles = dp; s.rem_tiles = s.tiles - dp;
     s.grid = dp + s.rem_tiles * split;
+    // XCD locality: what the 8 private L2s fetch from beyond them.  Runs that share activation rows: every XCD streams ALL the
+    // weights (8 W) and its own rows (A).  Runs that share an output-channel tile: an XCD streams the rows of all row tiles
+    // (g A, g = min(tiles_n, 8) groups) and 1/g of the weights (8 W / g).  The second form wins where the weights outweigh the
+    // activations: the small-M layers of a batch-1 forward.  Pure schedules only (work_item).
+    if ((dp == s.tiles || dp == 0) && s.tiles_n >= 2 && s.grid >= 16) {
+        const double wbytes = (double)d->Cout * K * (d->precision ? 6.0 : 4.0);
+        const double abytes = (double)d->N * d->H * d->W * desc_cin(d) * 4.0 + (d->c2 > 0 ? (double)M * d->c2 * 4.0 : 0.0);
+        const double g = s.tiles_n < 8 ? s.tiles_n : 8;
+        const int force = xcd_map_override();
+        s.nmajor = force >= 0 ? force : (8.0 * wbytes * (1.0 - 1.0 / g) > abytes * (g - 1.0) * 1.25 ? 1 : 0);
+    }
     // workspace = [kTicketBytes of arrival tickets, one int per K-sliced tile][rem_tiles * split slabs of BM x BN floats].
     // The ticket area has ONE size for every launch: launches that share a workspace must never see another launch's
     // slab bytes where they expect zeroed tickets.
@@ -1596,6 +1636,7 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
     p.ksteps = (p.K + kTiles[sc.tile].bk - 1) / kTiles[sc.tile].bk;
     p.tiles_m = sc.tiles_m; p.tiles_n = sc.tiles_n;
     p.dp_tiles = sc.dp_tiles; p.split = sc.split; p.ksteps_per_split = sc.ksteps_per_split; p.sk_q = sc.sk_q;
+    p.nmajor = sc.nmajor;
     if (sc.rem_tiles > 0)
         TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= sc.ws_bytes && tsod_aligned16(workspace), TSOD_ERR_WORKSPACE);
     p.tickets = static_cast<int *>(workspace);
