@@ -18,9 +18,10 @@ over 8 GPUs), weak scaling: every rank processes its own images, value = images 
 
 Two schedules are measured and BOTH are reported in the one JSON line:
   * serial     : one forward at a time on one stream (`serial`: images/s, ms per step = latency of a forward).  The
-                 `roofline` object belongs to this schedule: algorithmic conv FLOPs / per-kernel HIP-event time of the
-                 conv launches (on their launch stream) with the tile table tuned for it; its
-                 kernel_ms_per_forward is <= serial.ms_per_step, the step it is part of.
+                 `roofline` object belongs to this schedule: algorithmic conv FLOPs / HIP-event time of one pass over
+                 the conv launches in forward order (on their launch stream, tile table tuned for this schedule, cache
+                 state and launch boundaries of a forward: the figure agrees with the rocprofv3 kernel trace committed
+                 under profiles/); its kernel_ms_per_forward is <= serial.ms_per_step, the step it is part of.
   * in flight  : consecutive steps issued round-robin on --in-flight HIP streams (default 4, each with its own graph,
                  buffers and scratch): a batch-1 server with several requests in flight, the tail of one forward
                  overlapping the next one's kernels.  `value` / `ms_per_step` are this schedule's (with --in-flight 1
@@ -150,6 +151,26 @@ def conv_event_times(plan, reps=5):
         e1.synchronize()
         out.append(e0.elapsed_time(e1) / reps)
     return out
+
+
+def conv_sequence_time(plan, reps=10):
+    """HIP-event time (ms) of ONE pass over the plan's conv launches in forward order, back to back on the launch stream,
+    averaged over `reps` passes: every layer finds its input where the previous launch left it and its weights as cold as a
+    forward leaves them - the state the kernels run in inside the serial graph (the per-layer figure of conv_event_times, five
+    repeats of one launch on hot operands, reads ~10 % lower than the rocprofv3 kernel trace of the forward; this one agrees
+    with it).  Launch boundaries between the conv kernels are inside the interval, as they are inside a forward."""
+    from two_stage_object_detection_amd._ffi import stream_ptr
+    s = stream_ptr()
+    for st in plan.conv_steps:
+        st.fn(*st.args, s)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        for st in plan.conv_steps:
+            st.fn(*st.args, s)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def cpu_baseline(sd, backbone, x_cpu, reps):
@@ -512,16 +533,17 @@ def main(argv=None):
                 if args.tiles_file and rank == 0:
                     json.dump(tiles, open(args.tiles_file, "w"))
             plan.import_tiles(tiles["f32"])
-            ms32 = conv_event_times(plan)
+            ms32 = conv_sequence_time(plan)
             fl32 = sum(st.flops for st in plan.conv_steps)
-            f32_leg = {"bound": "mfma", "achieved": round(fl32 / (sum(ms32) * 1e-3) / 1e12, 3), "peak": F32_MFMA_PEAK_TFLOPS,
-                       "unit": "TFLOP/s", "frac": round(fl32 / (sum(ms32) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-                       "kernel_ms_per_forward": round(sum(ms32), 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
-                       "note": "the same conv launches with every layer pinned to the f32-MFMA kernels (serial per-kernel "
-                               "HIP-event times); not the timed path when --precision auto picks bf16x3"}
+            f32_leg = {"bound": "mfma", "achieved": round(fl32 / (ms32 * 1e-3) / 1e12, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+                       "unit": "TFLOP/s", "frac": round(fl32 / (ms32 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                       "kernel_ms_per_forward": round(ms32, 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
+                       "note": "the same conv launches with every layer pinned to the f32-MFMA kernels (one pass in forward order, "
+                               "HIP events); not the timed path when --precision auto picks bf16x3"}
         # ---- schedule 1: strictly serial (one graph, one stream) + the per-kernel roofline that belongs to it
         plan.import_tiles(tiles["serial"])
         conv_ms = conv_event_times(plan)
+        conv_seq_ms = conv_sequence_time(plan)
         if args.dump_layers and rank == 0:
             dump_layers(plan, args.dump_layers, conv_ms)
         conv_flops = sum(st.flops for st in plan.conv_steps)
@@ -579,7 +601,7 @@ def main(argv=None):
 
     if rank == 0:
         head = fly
-        conv_total_ms = sum(conv_ms)
+        conv_total_ms = conv_seq_ms                                       # one pass in forward order (agrees with the kernel trace)
         achieved = conv_flops / (conv_total_ms * 1e-3) / 1e12
         eff_peak = conv_flops / (ideal_ms * 1e-3) / 1e12               # FLOP-weighted harmonic peak of the layers' arithmetics
         n_bf = sum(precs)
@@ -626,6 +648,11 @@ def main(argv=None):
                          "kernel": f"conv_igemm_kernel / conv_dma_kernel (implicit GEMM; per layer f32 MFMA, bf16x3 MFMA register-staged, or bf16x3 MFMA fed by LDS-DMA), {len(conv_ms)} launches per forward",
                          "schedule": "serial", "flops_per_forward": conv_flops,
                          "kernel_ms_per_forward": round(conv_total_ms, 4),
+                         "kernel_ms_measured_as": "HIP events around one pass over the conv launches in forward order (cache state of a "
+                                                  "forward, launch boundaries included); `achieved` / `frac` use it",
+                         "kernel_ms_per_forward_isolated": round(sum(conv_ms), 4),
+                         "isolated_note": "sum over layers of 5 back-to-back repeats of each launch on hot operands (per-layer figures of "
+                                          "--dump-layers / --verbose): the optimistic bound",
                          "serial_ms_per_step": round(serial["ms_per_step"], 4),
                          "share_of_serial_step": round(conv_total_ms / serial["ms_per_step"], 4)},
             "throughput_mode": {"steps_in_flight": n_fly, "conv_tflops_per_step_time": round(step_flops / (head["ms_per_step"] * 1e-3) / 1e12, 3),
