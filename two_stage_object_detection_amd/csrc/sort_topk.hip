@@ -267,7 +267,7 @@ sort_topk_kernel(const float *__restrict__ keys, const float *__restrict__ boxes
 //                  r; the filtered keys (d >= d(-inf)) sort last and write the neutral rows.  Work B * n^2: small problems.
 //   FULL  = false: candidates = the n_sel keys sort_topk_kernel selected (sel[b][0 .. counts[b])), work B * n_sel^2.
 constexpr int kRankParts = 16;
-constexpr int kRankMaxPer = 1024;                  // candidates one wave ranks against per pass (its private LDS strip)
+constexpr int kRankMaxPer = 512;                   // candidates one wave ranks against per pass (its private LDS strip)
 template <bool FULL>
 __global__ void __launch_bounds__(64 * kRankParts)
 topk_rank_kernel(const float *__restrict__ keys, const float *__restrict__ boxes, const unsigned long long *__restrict__ sel, int P,
@@ -298,10 +298,10 @@ topk_rank_kernel(const float *__restrict__ keys, const float *__restrict__ boxes
     const int blocks = (n_cand + 63) / 64;
     const int bpp = (blocks + kRankParts - 1) / kRankParts;   // 64-blocks per strip
     const int lo = min(n_cand, part * bpp * 64), hi = min(n_cand, lo + bpp * 64);
-    unsigned less = 0, valid = 0;
+    unsigned less = 0, valid = 0, eq = 0;
     for (int p0 = lo; p0 < hi; p0 += kRankMaxPer) {            // (one pass unless a strip exceeds the LDS strip)
         const int p1 = min(hi, p0 + kRankMaxPer);
-        for (int j = p0 + lane; j < p0 + kRankMaxPer; j += 64) {
+        for (int j = p0 + lane; j < p0 + ((p1 - p0 + 63) & ~63); j += 64) {   // whole 64-blocks: the tail is padding
             unsigned dj = 0xFFFFFFFFu, ij = 0xFFFFFFFFu;      // padding: sorts after every real key
             if (j < p1) {
                 if (FULL) { dj = desc_key_bits(kbits[j]); }
@@ -328,14 +328,32 @@ topk_rank_kernel(const float *__restrict__ keys, const float *__restrict__ boxes
                     const uint4 d4 = dq[q];
                     less += (d4.x < md) + (d4.y < md) + (d4.z < md) + (d4.w < md);
                 }
-            } else {                                             // my own block (FULL), or a selection (any order of indices)
+            } else if (FULL) {                                   // my own block: the full (d, index) comparison
 #pragma unroll 4
                 for (int q = 0; q < 64; ++q) {
                     const unsigned dj = s_d[part][bl * 64 + q];
-                    const unsigned ij = FULL ? (unsigned)(jb + q) : s_i[part][bl * 64 + q];
-                    less += (dj < md || (dj == md && ij < mi)) ? 1u : 0u;
+                    less += (dj < md || (dj == md && (unsigned)(jb + q) < mi)) ? 1u : 0u;
+                }
+            } else {                                             // a selection (indices in any order): strict count + equal count
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uint4 d4 = dq[q];
+                    less += (d4.x < md) + (d4.y < md) + (d4.z < md) + (d4.w < md);
+                    eq += (d4.x == md) + (d4.y == md) + (d4.z == md) + (d4.w == md);
                 }
             }
+        }
+        if (!FULL) {
+            // ties: keys of this strip equal to a lane's key (its own position excluded) are ordered by source index.  Scores are
+            // f32 probabilities, so this pass is rare; it walks the strip only when some lane of the wave has such a tie.
+            const bool own_here = ci >= p0 && ci < p1;
+            if (__ballot(ci < n_cand && eq > (own_here ? 1u : 0u)) != 0ull) {
+                for (int q = 0; q < p1 - p0; ++q) {
+                    const unsigned dj = s_d[part][q], ij = s_i[part][q];
+                    less += (dj == md && ij < mi) ? 1u : 0u;
+                }
+            }
+            eq = 0;
         }
     }
     s_rank[part][lane] = less;
