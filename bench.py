@@ -89,6 +89,9 @@ def parse(argv=None):
                     "the in-flight tile table is tuned (default: --in-flight, i.e. 4: measured 697 -> 754 images/s on one box "
                     "against tuning with 2 copies; 6 and 8 are no better)")
     ap.add_argument("--autotune-splits", default=None, help="comma list restricting the K-slice candidates of the autotuner")
+    ap.add_argument("--autotune-in-sequence", type=int, default=5, help="serial tile table: the n fastest candidates of every layer "
+                    "(timed in isolation) are timed again as launches of the whole conv sequence and the winner THERE is pinned "
+                    "(cache state of a forward instead of self-warmed operands); 0 = isolated timing only")
     ap.add_argument("--in-flight", type=int, default=4, help="steps in flight: consecutive steps are issued round-robin on this "
                     "many HIP streams, each with its own graph and buffers (request-level pipelining of a batch-1 server)")
     ap.add_argument("--tiles-file", default=None, help="JSON cache of the autotuned (tile, split) tables {'serial': [...], "
@@ -482,7 +485,8 @@ def main(argv=None):
                               precisions=precs)
                 tiles["serial"] = tiles["in_flight"] = plan.export_tiles()
         elif not args.no_autotune:
-            plan.autotune(verbose=args.verbose and rank == 0, splits=splits, concurrent=1, precisions=precs)
+            plan.autotune(verbose=args.verbose and rank == 0, splits=splits, concurrent=1, precisions=precs,
+                          in_sequence=args.autotune_in_sequence)
             tiles["serial"] = plan.export_tiles()
             if n_fly > 1:                                              # objective of an overlapped server: two copies in flight
                 plan.autotune(verbose=False, splits=splits, concurrent=max(2, args.autotune_concurrent or n_fly), precisions=precs)

@@ -266,7 +266,8 @@ class Plan:
         return self
 
     # -- tile autotuning ----------------------------------------------------------------------
-    def autotune(self, reps: int = 3, verbose: bool = False, splits=None, concurrent: int = 1, precisions=None):
+    def autotune(self, reps: int = 3, verbose: bool = False, splits=None, concurrent: int = 1, precisions=None,
+                 in_sequence: int = 0):
         """Measure every (tile, split_k) candidate of every conv step on the real buffers with HIP
         events and keep the fastest.  Purely a speed choice: every candidate computes the same sums
         in the same k order per slab; only slab boundaries move.
@@ -274,13 +275,19 @@ class Plan:
         (per-copy time = elapsed / copies): the objective of a server that overlaps requests, where a
         schedule that fills the whole chip for one launch is not automatically the cheapest.
         ``precisions``: the arithmetics to choose from per layer (default: only what each step has now; (0, 1) lets the
-        f32-MFMA and the bf16x3 form of a layer compete - both are f32-accurate, see include/tsod.h)."""
+        f32-MFMA and the bf16x3 form of a layer compete - both are f32-accurate, see include/tsod.h).
+        ``in_sequence`` = n > 0 (serial objective only): a second look at the n fastest candidates of every layer INSIDE the
+        forward - the whole conv sequence is launched in order and only the layer under test is bracketed by HIP events, so
+        the candidate runs on the cache state a forward leaves (input just written by its producer, weights not touched since
+        the previous forward) instead of on operands kept hot by its own repetitions, which flatters the tiles that re-read
+        their weights most (measured: a layer3 1x1 conv chosen at 25 us isolated runs 33 us in the forward)."""
         self.graph = None
         concurrent = max(1, int(concurrent))
         bigs = [torch.zeros(512 << 20, dtype=torch.uint8, device=self.device) for _ in range(concurrent)]   # zero tickets
         big = bigs[0]
         side = [torch.cuda.Stream(self.device) for _ in range(concurrent - 1)]
         results = []
+        shortlist = []
         for st in self.conv_steps:
             d = st.desc
             K = d.KH * d.KW * sum(d.seg_len[i] for i in range(d.n_seg)) + max(0, int(d.c2))
@@ -349,13 +356,58 @@ class Plan:
             if best is None:
                 raise TsodError(f"autotune: no runnable (tile, split) candidate for {st.name}")
             st.choose(best[1], best[2], best[3])
+            shortlist.append([(tile, split, prec) for _, tile, split, prec in timed[:max(1, int(in_sequence))]])
             results.append((st.name, best[0], best[1], best[2], st.flops, best[3]))
             if verbose:
                 print(f"  {st.name:34s} {TILE_NAMES[best[1]]:8s} split {best[2]:3d} {_ffi.PREC_NAMES[best[3]]:6s} {best[0] * 1e3:8.1f} us "
                       f"{st.flops / best[0] / 1e9:7.1f} TF/s")
+        if in_sequence > 0 and concurrent == 1 and len(self.conv_steps) > 1:
+            results = self._refine_in_sequence(shortlist, results, big, reps=5, verbose=verbose)
         del big, bigs
         self.finalize()
         return results
+
+    def _refine_in_sequence(self, shortlist, results, big, reps, verbose):
+        """One sweep over the layers: each shortlisted candidate of layer i is timed as launch i of the whole conv sequence
+        (HIP events around that one launch, median of ``reps`` passes); the other layers run their current choice."""
+        import statistics
+        s = stream_ptr()
+
+        def args_of(st):
+            a = list(st.args)
+            a[st.ws_index], a[st.ws_index + 1] = ptr(big), big.numel()
+            return a
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        out = []
+        for i, st in enumerate(self.conv_steps):
+            cands = shortlist[i]
+            timed = []
+            for tile, split, prec in cands:
+                st.choose(tile, split, prec)
+                all_args = [args_of(t) for t in self.conv_steps]
+                ts = []
+                rc = 0
+                for _ in range(reps + 1):
+                    for j, t in enumerate(self.conv_steps):
+                        if j == i:
+                            e0.record()
+                        rc |= t.fn(*all_args[j], s)
+                        if j == i:
+                            e1.record()
+                    e1.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                if rc == 0:
+                    timed.append((statistics.median(ts[1:]), tile, split, prec))
+            timed.sort()
+            best = timed[0] if timed else (results[i][1], results[i][2], results[i][3], results[i][5])
+            st.choose(best[1], best[2], best[3])
+            out.append((st.name, best[0], best[1], best[2], st.flops, best[3]))
+            if verbose:
+                was = results[i]
+                note = "" if (was[2], was[3], was[5]) == (best[1], best[2], best[3]) else f"   (isolated pick: {TILE_NAMES[was[2]]} split {was[3]})"
+                print(f"  {st.name:34s} {TILE_NAMES[best[1]]:11s} split {best[2]:3d} {_ffi.PREC_NAMES[best[3]]:6s} {best[0] * 1e3:8.1f} us in sequence "
+                      f"{st.flops / best[0] / 1e9:7.1f} TF/s{note}")
+        return out
 
     def export_tiles(self):
         """[(name, tile, split_k, precision), ...] as currently pinned in the descriptors (tile 0 / split 0 = heuristic)."""
