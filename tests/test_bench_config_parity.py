@@ -42,9 +42,11 @@ def _tile_tables():
     """(file, key) of every committed table: round-1 files hold one list, later ones bench.py's
     {"serial": [...], "in_flight": [...]} pair."""
     out = []
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_autotuned_tiles_b1*.json"))):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_autotuned_tiles_b1*.json")) +
+                   glob.glob(os.path.join(ROOT, "profiles", "r*_b1_autotuned_tiles.json")))       # round 3 naming
+    for f in files:
         d = json.load(open(f))
-        out += [(f, None)] if isinstance(d, list) else [(f, k) for k in sorted(d)]
+        out += [(f, None)] if isinstance(d, list) else [(f, k) for k in sorted(d) if k != "heads"]   # heads: the two GEMMs outside the plan
     return out
 
 
@@ -120,6 +122,28 @@ def test_detector_after_plan_autotune_and_through_the_serving_path(dev, r50):
         plan.import_tiles(before)
         model.rpn._gemm_choice.clear()
         model.head._gemm_choice.clear()
+
+
+def test_detector_after_the_in_sequence_autotune(dev, r50):
+    """bench.py's SERIAL table (round 3): Plan.autotune(in_sequence=5) times the five fastest candidates of every layer again
+    as launches of the whole conv sequence and pins the winner there.  A speed choice like the first look: same RoIs."""
+    from two_stage_object_detection_amd.testing import compare_detector_outputs
+    model, sd, x, ref = r50
+    xg = x.to(dev)
+    with torch.inference_mode():
+        model(xg)
+        plan = model.extractor._plan_for(xg)
+        before = plan.export_tiles()
+        res = plan.autotune(reps=2, concurrent=1, precisions=(0, 1), in_sequence=5)
+        assert len(res) == len(plan.conv_steps) == 49 and all(r[1] > 0 for r in res)
+        tuned = plan.export_tiles()
+        assert [(n, t, s_, p) for n, _, t, s_, _, p in res] == tuned        # what it reports is what it pinned
+        got = [o.cpu() for o in model(xg)]
+        model.raise_if_error()
+        rep = compare_detector_outputs(got, ref)
+        print("in-sequence autotune", sorted({tuple(r[1:]) for r in tuned}), rep)
+        assert rep["ok"] and rep["rows_positional_mismatch"] <= 4 and rep["rows_unmatched"] == 0 and rep["class_mismatch"] == 0, rep
+        plan.import_tiles(before)
 
 
 @pytest.mark.parametrize("backbone,shape", [("resnet50", (1, 3, 800, 1333)), ("resnet50", (2, 3, 320, 448)), ("hardnet39", (2, 3, 320, 448))])

@@ -617,6 +617,47 @@ def test_conv_dual_source_second_source_must_be_whole_ksteps(ops, dev, C1, C2):
     assert ran > 0 and refused > 0
 
 
+def test_conv_xcd_run_orders_agree(dev):
+    """The order in which a launch's work items are dealt to the XCDs (runs that share activation rows / runs that share an
+    output-channel tile and K-slice: conv_igemm_f32.hip work_item) is a placement choice only: with the order pinned either
+    way (TSOD_XCD_NMAJOR, read once per process - hence child processes) every tile / K-slice schedule must produce the
+    same bits, and match the f64 CPU convolution."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import math, sys, torch
+import torch.nn.functional as F
+from two_stage_object_detection_amd import hip_ops as ops
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(5)
+outs = []
+for (H, W, Cin, Cout, k, prec, tiles) in ((25, 42, 512, 512, 3, 1, (22, 18, 17, 8)), (13, 21, 1024, 256, 1, 1, (22, 18, 3)), (25, 42, 256, 512, 1, 0, (3, 1, 6))):
+    x = torch.randn(1, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    ref = F.conv2d(x.double(), w.double(), None, 1, k // 2).float()
+    xn, wp = ops.nchw_to_nhwc(x.to(dev)), ops.pack_conv_weight(w.to(dev))
+    for tile in tiles:
+        for split in (1, 2, 3, 4):
+            y = ops.conv2d_nhwc(xn, wp, pad=k // 2, tile=tile, split_k=split, precision=prec)
+            assert (ops.nhwc_to_nchw(y).cpu() - ref).abs().max().item() <= 3e-6 * math.sqrt(Cin * k * k) + 1e-5, (tile, split)
+            outs.append(y.cpu())
+torch.save(outs, sys.argv[1])
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for mode in ("0", "1"):
+        path = os.path.join("/tmp", f"tsod_xcd_{os.getpid()}_{mode}.pt")
+        env = dict(os.environ, TSOD_XCD_NMAJOR=mode, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res.append(torch.load(path))
+        os.remove(path)
+    assert len(res[0]) == len(res[1]) >= 36
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("shape", [(8, 50, 84, 256, 256, 3), (8, 25, 42, 2048, 512, 1), (1, 100, 167, 128, 128, 3)])
 def test_dma_conv_tiles_at_full_layer_sizes(ops, dev, shape):
     """The LDS-DMA tiles (conv_dma_kernel) at layer sizes of BASELINE configs[1] / [4] (too large for an f64 CPU reference in

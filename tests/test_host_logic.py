@@ -237,3 +237,21 @@ def test_bench_compare_records_is_position_wise():
     nan = ref.clone()
     nan[0, 3, 4] = float("nan")
     assert not bench.compare_records(nan, ref)["ok"]
+
+
+def test_head_choices_roundtrip_as_json():
+    """FasterRCNN.head_choices / set_head_choices: the pinned (tile, K schedule, arithmetic) of the two GEMMs outside the
+    backbone plan travel as plain JSON (bench.py persists them beside the tile table and broadcasts them to every rank)."""
+    import json
+    torch.manual_seed(0)
+    m = FasterRCNN(num_classes=3, backbone="resnet50").eval()
+    assert m.head_choices() == {"rpn": {}, "head": {}}
+    m.rpn.__dict__.setdefault("_gemm_choice", {})[(8, 25, 42)] = (3, 12, 1)
+    m.head.__dict__.setdefault("_gemm_choice", {})[2400] = (10, 2, 1)
+    blob = json.loads(json.dumps(m.head_choices()))
+    assert blob == {"rpn": {"8x25x42": [3, 12, 1]}, "head": {"2400": [10, 2, 1]}}
+    m2 = FasterRCNN(num_classes=3, backbone="resnet50").eval()
+    m2.set_head_choices(blob)
+    assert m2.rpn._gemm_choice == {(8, 25, 42): (3, 12, 1)} and m2.head._gemm_choice == {2400: (10, 2, 1)}
+    m2.set_head_choices(None)                                   # nothing persisted: a no-op
+    assert m2.head_choices() == blob
