@@ -89,9 +89,11 @@ def parse(argv=None):
                     "the in-flight tile table is tuned (default: --in-flight, i.e. 4: measured 697 -> 754 images/s on one box "
                     "against tuning with 2 copies; 6 and 8 are no better)")
     ap.add_argument("--autotune-splits", default=None, help="comma list restricting the K-slice candidates of the autotuner")
-    ap.add_argument("--autotune-in-sequence", type=int, default=5, help="serial tile table: the n fastest candidates of every layer "
+    ap.add_argument("--autotune-in-sequence", type=int, default=None, help="serial tile table: the n fastest candidates of every layer "
                     "(timed in isolation) are timed again as launches of the whole conv sequence and the winner THERE is pinned "
-                    "(cache state of a forward instead of self-warmed operands); 0 = isolated timing only")
+                    "(cache state of a forward instead of self-warmed operands); 0 = isolated timing only.  Default 5 below batch 4 "
+                    "(measured on one box: serial 556 -> 567 images/s, conv time 1.636 -> 1.599 ms), 0 from batch 4 on (no effect "
+                    "there: 809 vs 810 images/s at batch 8 for 13 s more tuning)")
     ap.add_argument("--in-flight", type=int, default=4, help="steps in flight: consecutive steps are issued round-robin on this "
                     "many HIP streams, each with its own graph and buffers (request-level pipelining of a batch-1 server)")
     ap.add_argument("--tiles-file", default=None, help="JSON cache of the autotuned (tile, split) tables {'serial': [...], "
@@ -413,6 +415,8 @@ def main(argv=None):
     B = args.batch
     if args.check is None:
         args.check = world > 1                              # a driver-run --gpus N validates what it gathers
+    if args.autotune_in_sequence is None:
+        args.autotune_in_sequence = 5 if B < 4 else 0
 
     if args.rehearse_cpu:
         if world > 1:
