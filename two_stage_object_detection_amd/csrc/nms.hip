@@ -6,10 +6,11 @@
 //   utils/loc_bbox_iou.py:4-27  bbox_iou (eps in the denominator)
 //
 // Phase 1 (nms_mask_kernel, whole chip): mask[b][i][w] bit j = IoU(box i, box 64w+j) > thr, j > i.
-// Phase 2 (nms_scan_kernel, one wave per image): walk 64-box blocks in score order; inside a
-// block resolve suppression with a scalar bit scan over the diagonal words (readlane), then OR
-// the rows of the survivors into the per-lane `removed` words; stop as soon as n_post boxes are
-// kept (only keep[:n_post] is ever used).  Compiled with -ffp-contract=off: the IoU expression
+// Phase 2 (nms_scan_kernel, one wave per image): walk 64-box blocks in score order; a block starts
+// from the OR of one mask word per earlier survivor (gathered when the block is reached, requested
+// one block ahead), resolves suppression inside the block with a scalar bit scan over the diagonal
+// words (readlane) unless the diagonal words show no conflict at all; stop as soon as n_post boxes
+// are kept (only keep[:n_post] is ever used).  Compiled with -ffp-contract=off: the IoU expression
 // rounds exactly like the scalar f32 code in oracle/box_ops.c.
 #include "tsod_internal.h"
 
@@ -70,7 +71,25 @@ nms_mask_kernel(const float *__restrict__ boxes, const int *__restrict__ counts,
     if (i < n_max) mask[((long)b * n_max + i) * words + cb] = bits;
 }
 
-template <int WPL>  // mask words per lane = ceil(words / 64)
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, off);
+        const unsigned hi = __shfl_xor((unsigned)(v >> 32), off);
+        v |= ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+
+// Phase 2, one wave per image.  Block blk (64 boxes in score order) needs ONE mask word per earlier survivor: the word of
+// column block blk in that survivor's row.  They are gathered when the block is reached - lane l takes survivors l, l + 64, ...
+// of the keep list (at most n_post of them, so a handful of loads per lane) - instead of OR-ing every survivor's whole row
+// into per-lane `removed` words as soon as it is kept (rows x words loads, most of them for blocks the scan never reaches
+// once n_post boxes are kept).  Everything block blk + 1 needs is requested while block blk is being resolved:
+//   its diagonal word per row, the words of the survivors known so far, and - unconditionally - the words of all 64 rows
+//   of block blk (masked by that block's keep bits afterwards), so no load depends on the resolution it overlaps.
+// A block whose surviving rows do not suppress each other at all (one wave-wide OR of the diagonal words tells) keeps every
+// alive box without the bit-by-bit scan; otherwise the scalar scan walks the kept boxes as before.  Same greedy result.
 __global__ void __launch_bounds__(64)
 nms_scan_kernel(const float *__restrict__ boxes, int stride, const int *__restrict__ counts, int n_max, int words,
                 int n_post, const unsigned long long *__restrict__ mask, int *__restrict__ keep_idx,
@@ -80,72 +99,47 @@ nms_scan_kernel(const float *__restrict__ boxes, int stride, const int *__restri
     const int b = blockIdx.x;
     const int n = counts[b];
     const unsigned long long *mrow = mask + (long)b * n_max * words;
-    unsigned long long removed[WPL];
-#pragma unroll
-    for (int s = 0; s < WPL; ++s) removed[s] = 0ull;
-
     int total = 0;
     const int nblk = (n + 63) >> 6;
+    // state of the block about to be resolved
+    unsigned long long diag = lane < n ? mrow[(long)lane * words] : 0ull;     // block 0: its diagonal words; nothing removed yet
+    unsigned long long cur = 0ull;
     for (int blk = 0; blk < nblk && total < n_post; ++blk) {
-        // removed word of this block lives in lane (blk & 63), slot (blk >> 6)
-        unsigned long long cur = 0;
-#pragma unroll
-        for (int s = 0; s < WPL; ++s) {
-            const unsigned long long v = readlane64(removed[s], blk & 63);
-            if (s == (blk >> 6)) cur = v;
-        }
         const int row = blk * 64 + lane;
-        const unsigned long long diag = row < n ? mrow[(long)row * words + blk] : 0ull;
+        // ---- requests for block blk + 1 (none of them depends on this block's outcome)
+        const bool more = blk + 1 < nblk;
+        unsigned long long nx_diag = 0ull, nx_rows = 0ull, nx_pre = 0ull;
+        if (more) {
+            const int nrow = row + 64;
+            nx_diag = nrow < n ? mrow[(long)nrow * words + blk + 1] : 0ull;
+            nx_rows = row < n ? mrow[(long)row * words + blk + 1] : 0ull;
+            for (int i = lane; i < min(total, n_post); i += 64) nx_pre |= mrow[(long)s_keep[i] * words + blk + 1];
+        }
+        // ---- resolve this block
         const int in_blk = min(64, n - blk * 64);
         unsigned long long alive = ~cur & (in_blk == 64 ? ~0ull : ((1ull << in_blk) - 1ull));
-        unsigned long long kept = 0;
-        while (alive) {  // wave-uniform scalar loop: at most one iteration per kept box
-            const int bit = __ffsll((long long)alive) - 1;
-            kept |= 1ull << bit;
-            alive &= ~(1ull << bit);
-            alive &= ~readlane64(diag, bit);
+        unsigned long long kept;
+        const unsigned long long conflicts = wave_or64(((alive >> lane) & 1ull) ? (diag & alive) : 0ull);
+        if (conflicts == 0ull) {
+            kept = alive;                              // no alive box of the block suppresses another one
+        } else {
+            kept = 0ull;
+            while (alive) {                            // wave-uniform scalar loop: one iteration per kept box
+                const int bit = __ffsll((long long)alive) - 1;
+                kept |= 1ull << bit;
+                alive &= ~(1ull << bit);
+                alive &= ~readlane64(diag, bit);
+            }
         }
         if ((kept >> lane) & 1ull) {
             const int pos = total + __popcll(kept & ((1ull << lane) - 1ull));
             if (pos < n_post) s_keep[pos] = row;
         }
         total += __popcll(kept);
-        if (total >= n_post || kept == 0ull) continue;
-        // OR the survivors' rows into the removed words of the later blocks
-#pragma unroll
-        for (int s = 0; s < WPL; ++s) {
-            const int w = lane + 64 * s;
-            if (w < words && w > blk) {
-                unsigned long long acc = 0;
-                const unsigned long long *col = mrow + (long)blk * 64 * words + w;
-                if (__popcll(kept) >= 32) {
-                    // most of the block survived: sweep all 64 rows, 16 loads in flight
-#pragma unroll 16
-                    for (int bit = 0; bit < 64; ++bit) {
-                        const int r = blk * 64 + bit;
-                        const unsigned long long v = r < n ? col[(long)bit * words] : 0ull;
-                        acc |= ((kept >> bit) & 1ull) ? v : 0ull;
-                    }
-                } else {
-                    // few survivors: only their rows matter - walk the set bits of `kept` (wave-uniform), eight rows
-                    // in flight per round
-                    unsigned long long k = kept;
-                    while (k) {
-                        int b[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            b[q] = k ? __ffsll((long long)k) - 1 : -1;
-                            k &= k - 1;                   // 0 stays 0
-                        }
-                        unsigned long long v[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = b[q] >= 0 ? col[(long)b[q] * words] : 0ull;
-                        acc |= ((v[0] | v[1]) | (v[2] | v[3])) | ((v[4] | v[5]) | (v[6] | v[7]));
-                    }
-                }
-                removed[s] |= acc;
-            }
-        }
+        // ---- what the next block starts from
+        if (more) cur = wave_or64(nx_pre | (((kept >> lane) & 1ull) ? nx_rows : 0ull));
+        diag = nx_diag;
+        __syncthreads();                               // (one wave: orders the keep list's LDS writes before the next gather)
     }
     __syncthreads();
     const int n_kept = min(total, n_post);
@@ -215,17 +209,8 @@ int launch_nms(const float *boxes, int stride, int label_col, const int32_t *cou
         hipLaunchKernelGGL((nms_mask_kernel<6, -1>), dim3(words, words, B), dim3(64), 0, s, boxes, counts, n_max, words,
                            iou_thr, mask);
     const size_t lds = (size_t)n_post * sizeof(int);
-    const int wpl = (words + 63) / 64;
-#define TSOD_NMS_SCAN(W)                                                                                                \
-    hipLaunchKernelGGL(nms_scan_kernel<W>, dim3(B), dim3(64), lds, s, boxes, stride, counts, n_max, words, n_post, mask, \
-                       keep_idx, rois, n_kept, status, pad)
-    switch (wpl) {
-        case 1: TSOD_NMS_SCAN(1); break;
-        case 2: TSOD_NMS_SCAN(2); break;
-        case 3: TSOD_NMS_SCAN(3); break;
-        default: TSOD_NMS_SCAN(4); break;
-    }
-#undef TSOD_NMS_SCAN
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), lds, s, boxes, stride, counts, n_max, words, n_post, mask, keep_idx,
+                       rois, n_kept, status, pad);
     return tsod_launch_status();
 }
 }  // namespace
