@@ -94,6 +94,10 @@ def parse(argv=None):
                     "(cache state of a forward instead of self-warmed operands); 0 = isolated timing only.  Default 5 below batch 4 "
                     "(measured on one box: serial 556 -> 567 images/s, conv time 1.636 -> 1.599 ms), 0 from batch 4 on (no effect "
                     "there: 809 vs 810 images/s at batch 8 for 13 s more tuning)")
+    ap.add_argument("--autotune-in-flight-refine", type=int, default=None, help="in-flight tile table: the n fastest candidates of every "
+                    "layer are tried again while all --in-flight streams run the whole conv sequence, staggered around it (the load "
+                    "of a pipelined server), and the one that makes those passes fastest is pinned; 0 = first look only (copies of "
+                    "one layer side by side).  Default 3 below batch 4, 0 from batch 4 on")
     ap.add_argument("--in-flight", type=int, default=4, help="steps in flight: consecutive steps are issued round-robin on this "
                     "many HIP streams, each with its own graph and buffers (request-level pipelining of a batch-1 server)")
     ap.add_argument("--tiles-file", default=None, help="JSON cache of the autotuned (tile, split) tables {'serial': [...], "
@@ -417,6 +421,8 @@ def main(argv=None):
         args.check = world > 1                              # a driver-run --gpus N validates what it gathers
     if args.autotune_in_sequence is None:
         args.autotune_in_sequence = 5 if B < 4 else 0
+    if args.autotune_in_flight_refine is None:
+        args.autotune_in_flight_refine = 3 if B < 4 else 0
 
     if args.rehearse_cpu:
         if world > 1:
@@ -492,9 +498,19 @@ def main(argv=None):
             plan.autotune(verbose=args.verbose and rank == 0, splits=splits, concurrent=1, precisions=precs,
                           in_sequence=args.autotune_in_sequence)
             tiles["serial"] = plan.export_tiles()
-            if n_fly > 1:                                              # objective of an overlapped server: two copies in flight
-                plan.autotune(verbose=False, splits=splits, concurrent=max(2, args.autotune_concurrent or n_fly), precisions=precs)
+            if n_fly > 1:                                              # objective of an overlapped server: copies in flight
+                plan.autotune(verbose=False, splits=splits, concurrent=max(2, args.autotune_concurrent or n_fly), precisions=precs,
+                              keep_shortlist=args.autotune_in_flight_refine)
                 tiles["in_flight"] = plan.export_tiles()
+                if args.autotune_in_flight_refine > 0 and plan.last_shortlist:
+                    # second look on the real shape of the load: every slot's stream runs the whole conv sequence, staggered
+                    from two_stage_object_detection_amd.engine import refine_in_flight
+                    slot_plans = [plan]
+                    for sl in range(1, n_fly):
+                        model(x, slot=sl)
+                        slot_plans.append(model.extractor._plan_for(x, sl))
+                        slot_plans[-1].import_tiles(tiles["in_flight"])
+                    tiles["in_flight"] = refine_in_flight(slot_plans, plan.last_shortlist, verbose=args.verbose and rank == 0)
             else:
                 tiles["in_flight"] = tiles["serial"]
         if "heads" in tiles:

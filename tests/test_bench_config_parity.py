@@ -146,6 +146,43 @@ def test_detector_after_the_in_sequence_autotune(dev, r50):
         plan.import_tiles(before)
 
 
+def test_detector_after_the_in_flight_refinement(dev, r50):
+    """bench.py's IN-FLIGHT table (round 3): after the first look (copies of one layer side by side) the three fastest
+    candidates of every layer are tried again while all slots' streams run the whole conv sequence staggered around it
+    (engine.refine_in_flight).  The table it returns is pinned in every slot's plan; served through InFlightDetector it must
+    give the oracle's RoIs like any other tile table."""
+    from two_stage_object_detection_amd.engine import refine_in_flight
+    from two_stage_object_detection_amd.serving import InFlightDetector
+    from two_stage_object_detection_amd.testing import compare_detector_outputs
+    model, sd, x, ref = r50
+    xg = x.to(dev)
+    with torch.inference_mode():
+        model(xg)
+        plan = model.extractor._plan_for(xg)
+        before = plan.export_tiles()
+        plan.autotune(reps=2, concurrent=3, precisions=(0, 1), keep_shortlist=2)
+        assert plan.last_shortlist is not None and len(plan.last_shortlist) == 49 and all(1 <= len(c) <= 2 for c in plan.last_shortlist)
+        first = plan.export_tiles()
+        plans = [plan]
+        for sl in (1, 2):
+            model(xg, slot=sl)
+            plans.append(model.extractor._plan_for(xg, sl))
+            plans[-1].import_tiles(first)
+        table = refine_in_flight(plans, plan.last_shortlist, rounds=2)
+        assert [t[0] for t in table] == [t[0] for t in first]
+        assert all(pl.export_tiles() == table for pl in plans)                      # pinned in every slot
+        assert all(tuple(t[1:]) in [tuple(c) for c in plan.last_shortlist[i]] or t == first[i] for i, t in enumerate(table))
+        server = InFlightDetector(model, xg, depth=3, tiles=table)
+        for t in [server.submit(xg) for _ in range(6)][3:]:
+            r = compare_detector_outputs([o.cpu() for o in server.result(t)][:4], ref)
+            assert r["ok"] and r["rows_positional_mismatch"] <= 4 and r["rows_unmatched"] == 0 and r["class_mismatch"] == 0, (t, r)
+        server.drain()
+        for pl in plans:
+            pl.import_tiles(before)
+        model.extractor.drop_plan(slot=1)
+        model.extractor.drop_plan(slot=2)
+
+
 @pytest.mark.parametrize("backbone,shape", [("resnet50", (1, 3, 800, 1333)), ("resnet50", (2, 3, 320, 448)), ("hardnet39", (2, 3, 320, 448))])
 def test_detector_with_every_dense_conv_in_bf16x3(dev, backbone, shape):
     """SURVEY 8(f) rank 4, second half: the reduced-precision (bf16x3) conv path, gated by the SAME parity suite: the

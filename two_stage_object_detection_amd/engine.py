@@ -267,7 +267,7 @@ class Plan:
 
     # -- tile autotuning ----------------------------------------------------------------------
     def autotune(self, reps: int = 3, verbose: bool = False, splits=None, concurrent: int = 1, precisions=None,
-                 in_sequence: int = 0):
+                 in_sequence: int = 0, keep_shortlist: int = 0):
         """Measure every (tile, split_k) candidate of every conv step on the real buffers with HIP
         events and keep the fastest.  Purely a speed choice: every candidate computes the same sums
         in the same k order per slab; only slab boundaries move.
@@ -356,13 +356,14 @@ class Plan:
             if best is None:
                 raise TsodError(f"autotune: no runnable (tile, split) candidate for {st.name}")
             st.choose(best[1], best[2], best[3])
-            shortlist.append([(tile, split, prec) for _, tile, split, prec in timed[:max(1, int(in_sequence))]])
+            shortlist.append([(tile, split, prec) for _, tile, split, prec in timed[:max(1, int(in_sequence), int(keep_shortlist))]])
             results.append((st.name, best[0], best[1], best[2], st.flops, best[3]))
             if verbose:
                 print(f"  {st.name:34s} {TILE_NAMES[best[1]]:8s} split {best[2]:3d} {_ffi.PREC_NAMES[best[3]]:6s} {best[0] * 1e3:8.1f} us "
                       f"{st.flops / best[0] / 1e9:7.1f} TF/s")
+        self.last_shortlist = shortlist if keep_shortlist > 0 else None      # (``keep_shortlist`` fastest per layer: refine_in_flight)
         if in_sequence > 0 and concurrent == 1 and len(self.conv_steps) > 1:
-            results = self._refine_in_sequence(shortlist, results, big, reps=5, verbose=verbose)
+            results = self._refine_in_sequence([c[:in_sequence] for c in shortlist], results, big, reps=5, verbose=verbose)
         del big, bigs
         self.finalize()
         return results
@@ -431,6 +432,88 @@ class Plan:
             lib().tsod_conv2d_resolve(byref(st.desc), byref(t), byref(s))
             out.append((st.name, t.value, s.value))
         return out
+
+
+def refine_in_flight(plans, shortlist, rounds: int = 4, verbose: bool = False):
+    """Second look at a tile table whose objective is SEVERAL requests in flight (serving.InFlightDetector): ``plans`` are the
+    backbone plans of the server's slots (same geometry, own buffers and workspaces), ``shortlist[i]`` the candidates of conv
+    layer i (``Plan.autotune(..., keep_shortlist=k)``: its k fastest by the first look, which times copies of ONE layer side by
+    side on hot operands).  Here every slot's stream runs the whole conv sequence, the slots STAGGERED around it (slot s starts
+    s / n of the way in, wrapping), so that at any moment the chip holds launches of different layers, as a pipelined server
+    does; the time of ``rounds`` such passes is the figure of merit.  One sweep over the layers: the candidate that makes the
+    passes fastest is pinned in every plan.  Stale activations are read where the rotation puts a consumer ahead of its
+    producer - timing only; the plans are finalized (workspaces re-bound) on return.  Returns the table (export_tiles)."""
+    import statistics
+    n = len(plans)
+    dev = plans[0].device
+    L = len(plans[0].conv_steps)
+    streams = [torch.cuda.Stream(dev) for _ in range(n)]
+    offs = [(s * L) // n for s in range(n)]
+    cur = torch.cuda.current_stream(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    bigs = [torch.zeros(512 << 20, dtype=torch.uint8, device=dev) for _ in range(n)]        # zero tickets, any candidate's slabs
+
+    def all_args():
+        out = []
+        for pl, big in zip(plans, bigs):
+            rows = []
+            for st in pl.conv_steps:
+                a = list(st.args)
+                a[st.ws_index], a[st.ws_index + 1] = ptr(big), big.numel()
+                rows.append((st.fn, a))
+            out.append(rows)
+        return out
+
+    def measure(args):
+        ts = []
+        for _ in range(3):
+            for st_ in streams:
+                st_.wait_stream(cur)
+            e0.record(cur)
+            for st_ in streams:
+                st_.wait_event(e0)
+            rc = 0
+            for _r in range(rounds):
+                for j in range(L):
+                    for s_, st_ in enumerate(streams):
+                        fn, a = args[s_][(j + offs[s_]) % L]
+                        rc |= fn(*a, st_.cuda_stream)
+            for st_ in streams:
+                cur.wait_stream(st_)
+            e1.record(cur)
+            e1.synchronize()
+            if rc != 0:
+                return None
+            ts.append(e0.elapsed_time(e1))
+        return statistics.median(ts)
+
+    base = measure(all_args())
+    changed = 0
+    for i in range(L):
+        keep = (int(plans[0].conv_steps[i].desc.tile), int(plans[0].conv_steps[i].desc.split_k), int(plans[0].conv_steps[i].desc.precision))
+        best_t, best_c = base, keep
+        for cand in shortlist[i]:
+            if tuple(cand) == keep:
+                continue
+            for pl in plans:
+                pl.conv_steps[i].choose(*cand)
+            t = measure(all_args())
+            if t is not None and t < best_t * 0.997:                # (0.3 %: below that the passes' own noise decides)
+                best_t, best_c = t, tuple(cand)
+        for pl in plans:
+            pl.conv_steps[i].choose(*best_c)
+        if best_c != keep:
+            changed += 1
+            if verbose:
+                print(f"  in flight: {plans[0].conv_steps[i].name:34s} {TILE_NAMES[keep[0]]} split {keep[1]} -> {TILE_NAMES[best_c[0]]} split {best_c[1]}"
+                      f"   ({base / rounds / n * 1e3:.1f} -> {best_t / rounds / n * 1e3:.1f} us of conv time per forward)")
+        base = best_t
+    del bigs
+    for pl in plans:
+        pl.finalize()
+    if verbose:
+        print(f"  in flight: {changed} of {L} picks changed; conv time per forward with {n} staggered streams {base / rounds / n * 1e3:.1f} us")
+    return plans[0].export_tiles()
 
 
 def _invalidate_after_load(module, incompatible_keys):
