@@ -1,6 +1,6 @@
 """Time the depthwise 3x3 kernel on the HarDNet shapes (stride-4 maps of an 800x1333 image).
 
-    python scripts/dw_bench.py [H W]
+    python scripts/dw_bench.py [H W [N]]
 
 Prints microseconds and the algorithmic HBM rate (read C + write C floats per pixel) per shape; the
 "slice" rows write into a channel slice of a wider buffer, as the zero-copy concat does.
@@ -15,14 +15,15 @@ from two_stage_object_detection_amd import hip_ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (200, 334)
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 
 
 def bench(C, out_pitch, stride, reps=20):
-    x = torch.randn(1, H, W, C, device=dev)
+    x = torch.randn(N, H, W, C, device=dev)
     w = torch.randn(3, 3, C, device=dev)
     sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
-    out = torch.zeros(1, OH, OW, out_pitch, device=dev)
+    out = torch.zeros(N, OH, OW, out_pitch, device=dev)
     flush = torch.empty(96 << 20, device=dev)            # 384 MB: evicts L2 + Infinity Cache between runs
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
     ts = []
@@ -35,7 +36,7 @@ def bench(C, out_pitch, stride, reps=20):
         ts.append(e0.elapsed_time(e1) * 1e3)
     ts.sort()
     t = ts[len(ts) // 2]
-    byt = 4.0 * C * (H * W + OH * OW)
+    byt = 4.0 * N * C * (H * W + OH * OW)
     print(f"C={C:5d} out_pitch={out_pitch:5d} stride={stride}  {t:8.1f} us  {byt / t / 1e6:6.2f} TB/s")
 
 

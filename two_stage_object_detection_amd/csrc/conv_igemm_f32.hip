@@ -62,6 +62,9 @@ struct ConvParams {
     // `split` K-slices, one workgroup per (tile, slice), partial sums reduced by conv_reduce_kernel
     int dp_tiles, split, ksteps_per_split;
     int sk_q;                     // > 0: balanced schedule (conv_dma_kernel): K-steps per workgroup of the tile-major K-step sequence
+    int cmajor;                   // conv_dma_kernel, KH*KW > 1: K-steps run in (32-channel block, tap) order instead of (tap, channels):
+                                  // a pixel's 128-byte line is used by all taps that touch it within KH*KW steps (L2-resident),
+                                  // and a K-slice reads only its channel blocks.  Which step of the SAME weight image a K-step is.
     int nmajor;                   // 1: workgroups of one XCD share an output-channel tile (and K-slice): the weights it streams
                                   //    stay in that XCD's L2 and are fetched from beyond it once, not once per XCD (small-M layers,
                                   //    where the weights outweigh the activations); 0: they share activation rows (the default)
@@ -1035,12 +1038,19 @@ conv_dma_kernel(const ConvParams p) {
     // State of the stage being ISSUED, all wave-uniform (scalar unit): its K-step, filter tap, channel base, the byte offset
     // that tap adds to a pixel's base address, which source it reads and the two descriptors (zero records once the stage lies
     // past this workgroup's K range: a null DMA, no memory traffic, zeros written, so that the counted waits never change).
+    // Step order of the first source: (tap, channels) = the order of k in the weight image, or under p.cmajor (32-channel
+    // block, tap, 16-channel half when BK == 16): the same steps in another sequence, so only which k-groups of the image a
+    // step fetches changes (u_woff below).
     int u_kt = kt_begin, u_kh, u_kw, u_ci;
     {
-        const int kb = kt_begin * BK, seg0 = kb / p.Cin;
-        u_ci = kb - seg0 * p.Cin;
-        u_kh = seg0 / p.KW;
-        u_kw = seg0 - u_kh * p.KW;
+        constexpr int SUB = 32 / BK;
+        const int blk = kt_begin / SUB, sub = kt_begin - blk * SUB, taps = p.KH * p.KW;
+        const int cb = blk / taps, tap_c = blk - cb * taps;      // channel-block-major
+        const int kb = kt_begin * BK, tap_t = kb / p.Cin;        // tap-major
+        const int tap = p.cmajor ? tap_c : tap_t;
+        u_ci = p.cmajor ? cb * 32 + sub * BK : kb - tap_t * p.Cin;
+        u_kh = tap / p.KW;
+        u_kw = tap - u_kh * p.KW;
     }
     unsigned u_delta, u_woff;
     bool u_second;
@@ -1049,7 +1059,7 @@ conv_dma_kernel(const ConvParams p) {
         const bool live = u_kt < kt_end;
         u_second = u_kt * BK >= p.K1;                             // second source: a 1x1 tap, always inside the image
         u_delta = u_second ? (unsigned)((u_kt * BK - p.K1) * 4) : (unsigned)(((u_kh * p.W + u_kw) * p.in_pitch + u_ci) * 4);
-        u_woff = (unsigned)(u_kt * (BK / 8) * 48);
+        u_woff = (p.cmajor && !u_second) ? (unsigned)((((u_kh * p.KW + u_kw) * p.Cin + u_ci) >> 3) * 48) : (unsigned)(u_kt * (BK / 8) * 48);
         // (readfirstlane: the divergence analysis loses sight of the uniformity of this loop-carried state, and a descriptor
         //  must sit in scalar registers)
 #pragma unroll
@@ -1063,8 +1073,17 @@ conv_dma_kernel(const ConvParams p) {
     stage_state();
     auto advance_stage = [&]() {
         ++u_kt;
-        u_ci += BK;
-        if (u_ci >= p.Cin) { u_ci = 0; if (++u_kw == p.KW) { u_kw = 0; ++u_kh; } }
+        // (selects, not nested updates: written as branches these three scalars end up in scratch memory, and a scratch access
+        //  is a VMEM operation in the middle of the hand-counted vmcnt)
+        const int ci1 = u_ci + BK, kw1 = u_kw + 1, kh1 = u_kh + 1;
+        // tap-major: the tap is done when its channels are; channel-block-major: when this tap's 32-channel block is, and the
+        // block only moves on after the last tap
+        const bool tap_done = p.cmajor ? (ci1 & 31) == 0 : ci1 >= p.Cin;
+        const bool row_done = tap_done && kw1 == p.KW;
+        const bool all_taps = row_done && kh1 == p.KH;
+        u_ci = !tap_done ? ci1 : (p.cmajor ? (all_taps ? ci1 : ci1 - 32) : 0);
+        u_kw = !tap_done ? u_kw : (row_done ? 0 : kw1);
+        u_kh = !row_done ? u_kh : ((p.cmajor && all_taps) ? 0 : kh1);
         stage_state();
     };
     // piece I of the stage being issued into ring slot `slot` (branch-free: selects only; I is a compile-time constant so
@@ -1398,6 +1417,16 @@ int xcd_map_override() {
     return v;
 }
 
+// TSOD_KSTEP_TAPMAJOR = 1 keeps the LDS-DMA tiles on the weight image's own K-step order, (tap, channels), for experiments
+// (unset: channel blocks outermost wherever a filter has more than one tap, ConvParams::cmajor)
+int kstep_order_override() {
+    static const int v = [] {
+        const char *e = getenv("TSOD_KSTEP_TAPMAJOR");
+        return e != nullptr && atoi(e) != 0 ? 0 : 1;
+    }();
+    return v;
+}
+
 int g_cu_count = 0;
 int cu_count() {
     if (g_cu_count == 0) {
@@ -1637,6 +1666,7 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
     p.tiles_m = sc.tiles_m; p.tiles_n = sc.tiles_n;
     p.dp_tiles = sc.dp_tiles; p.split = sc.split; p.ksteps_per_split = sc.ksteps_per_split; p.sk_q = sc.sk_q;
     p.nmajor = sc.nmajor;
+    p.cmajor = (kTiles[sc.tile].dma && d->KH * d->KW > 1 && p.Cin % 32 == 0 && kstep_order_override() != 0) ? 1 : 0;
     if (sc.rem_tiles > 0)
         TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= sc.ws_bytes && tsod_aligned16(workspace), TSOD_ERR_WORKSPACE);
     p.tickets = static_cast<int *>(workspace);

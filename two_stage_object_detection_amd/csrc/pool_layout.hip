@@ -11,11 +11,25 @@
 
 namespace {
 
+// Stencil kernels walk the image in row-major blocks, and vertically adjacent blocks read the same input rows.  Blocks b,
+// b + 8, ... share an XCD (private L2; observed round-robin placement - a speed matter only), so plain block order hands
+// neighbouring rows to DIFFERENT L2s and every shared row is fetched from beyond the L2 once per XCD that touches it
+// (measured: the 3x3/s2 max pool moved 1.44x its algorithmic bytes).  With a grid of 8 * per blocks, XCD x takes the
+// contiguous band [x * per, (x + 1) * per) of the logical block order: a shared row is fetched once, by the band that owns it.
+__device__ __forceinline__ long xcd_band_block() {
+    const long per = gridDim.x >> 3;
+    return (long)(blockIdx.x & 7) * per + (long)(blockIdx.x >> 3);
+}
+inline unsigned xcd_band_grid(long blocks) { return (unsigned)((blocks + 7) / 8 * 8); }
+
 __global__ void __launch_bounds__(256)
 maxpool3x3s2_kernel(const float *__restrict__ in, int N, int H, int W, int C4, int in_pitch, int OH, int OW,
-                    float *__restrict__ out, int out_pitch) {
+                    float *__restrict__ out, int out_pitch, int banded) {
     const long total = (long)N * OH * OW * C4;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    // banded: one pass, logical block = this XCD's band; else a grid-stride loop over the plain order
+    const long first = (banded ? xcd_band_block() : (long)blockIdx.x) * blockDim.x + threadIdx.x;
+    const long stride = banded ? total : (long)gridDim.x * blockDim.x;
+    for (long t = first; t < total; t += stride) {
         const int c4 = (int)(t % C4);
         long u = t / C4;
         const int ow = (int)(u % OW);
@@ -55,7 +69,7 @@ dwconv3x3_kernel(const float *__restrict__ in, int N, int H, int W, int C4, int 
     const int OWG = (OW + OUTS - 1) / OUTS;
     const int ORB = (OH + R - 1) / R;
     const long total = (long)N * ORB * OWG * C4;
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (XCD bands of the block order measured no faster here)
     if (t >= total) return;
     const int c4 = (int)(t % C4);
     long u = t / C4;
@@ -271,9 +285,10 @@ extern "C" int tsod_maxpool3x3s2_f32(const float *in, int32_t N, int32_t H, int3
                  TSOD_ERR_ALIGNMENT);
     TSOD_REQUIRE(tsod_aligned16(in) && tsod_aligned16(out), TSOD_ERR_ALIGNMENT);
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
-    const long total = (long)N * OH * OW * (C / 4);
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, tsod_stream(stream), in, N,
-                       H, W, C / 4, in_pitch, OH, OW, out, out_pitch);
+    const long total = (long)N * OH * OW * (C / 4), blocks = (total + 255) / 256;
+    const int banded = blocks >= 64 && blocks <= (1L << 22);     // small maps: plain order (a band would be a few blocks)
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(banded ? xcd_band_grid(blocks) : grid_for(total, 256, 8192)), dim3(256), 0,
+                       tsod_stream(stream), in, N, H, W, C / 4, in_pitch, OH, OW, out, out_pitch, banded);
     return tsod_launch_status();
 }
 
