@@ -62,6 +62,7 @@ struct ConvParams {
     // `split` K-slices, one workgroup per (tile, slice), partial sums reduced by conv_reduce_kernel
     int dp_tiles, split, ksteps_per_split;
     int sk_q;                     // > 0: balanced schedule (conv_dma_kernel): K-steps per workgroup of the tile-major K-step sequence
+    int ci_wrap;                  // channels a tap's run of K-steps covers before the next tap: Cin (tap-major), 32 (cmajor)
     int cmajor;                   // conv_dma_kernel, KH*KW > 1: K-steps run in (32-channel block, tap) order instead of (tap, channels):
                                   // a pixel's 128-byte line is used by all taps that touch it within KH*KW steps (L2-resident),
                                   // and a K-slice reads only its channel blocks.  Which step of the SAME weight image a K-step is.
@@ -859,6 +860,9 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
 // Requires one channel segment, Cin % BK == 0 (a stage lies inside one filter tap) and, with a second source, K1 % BK == 0.
 // Measurements and the instruction-level findings behind this layout: DESIGN.md 4.3, scripts/micro/bf16x3_dma_probe.hip.
 typedef int v4i32 __attribute__((ext_vector_type(4)));
+#ifdef TSOD_DIAG_NODMA
+__device__ int g_nodma_steps = 3;   // (a load the compiler cannot fold: with a constant here it proves the loop's descriptors null)
+#endif
 
 __device__ __forceinline__ v4i32 dma_rsrc(const void *ptr, unsigned bytes) {
     v4i32 r; const unsigned long long a = (unsigned long long)ptr;
@@ -872,15 +876,19 @@ __device__ __forceinline__ v4i32 dma_rsrc(const void *ptr, unsigned bytes) {
 #ifndef TSOD_DMA_POLICY_B
 #define TSOD_DMA_POLICY_B ""
 #endif
+// (the LDS destination = piece base + ring-slot offset is added INTO m0 by the statement itself: one scalar instruction
+//  instead of an add and a move - scalar instructions are what the K loop is short of)
 template <int WEIGHTS = 0>
-__device__ __forceinline__ void dma16(unsigned voff, v4i32 rsrc, unsigned soff, unsigned lds_dst) {
+__device__ __forceinline__ void dma16(unsigned voff, v4i32 rsrc, unsigned soff, unsigned lds_dst, unsigned slot_off) {
     if (WEIGHTS)
-        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen" TSOD_DMA_POLICY_B " lds"
-                     :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+        asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen" TSOD_DMA_POLICY_B " lds"
+                     :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst), "s"(slot_off) : "memory", "scc");
     else
-        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen" TSOD_DMA_POLICY_A " lds"
-                     :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+        asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen" TSOD_DMA_POLICY_A " lds"
+                     :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst), "s"(slot_off) : "memory", "scc");
 }
+// s_waitcnt lgkmcnt(N) that the uses of `x` (an LDS read's destination) cannot be scheduled above
+template <int N, typename T> __device__ __forceinline__ void wait_lgkm_for(T &x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); }
 template <int OFF, typename T> __device__ __forceinline__ void lds_read16(T &out, unsigned addr) {
@@ -923,6 +931,8 @@ __device__ __forceinline__ void gap_read(f32x16 &c, const bf16x8 &a, const bf16x
 }
 
 constexpr int dma_stage_bytes(int bm, int bk, int bn = 128) { return bm * bk * 4 + 3 * bn * bk * 2; }
+constexpr int kDmaTabEntries = 640;   // K-steps of one workgroup's K range + ring depth + 1 (tile_ok_for keeps K / bk + 8 below it)
+constexpr unsigned kDmaSecondBit = 0x80000000u;   // validity-mask bit of the second source's 1x1 tap (filter taps use bits 0..30)
 
 // WAVES_N = 2: two columns of waves, BN = 256 - both read (and split) the same activation rows, each its own 128 output
 // channels: more FLOP per byte fetched from beyond the CU (the activation stage is shared) at the same 128-row granularity
@@ -945,7 +955,18 @@ conv_dma_kernel(const ConvParams p) {
     constexpr bool B_PAD = B_PIECES % WAVES != 0;
     constexpr int PATCHES = WAVES * 32 * kPatchLD * 4;
     static_assert(S * STAGE >= PATCHES && S * STAGE >= WAVES * 2 * 16 * 64 * 4, "epilogue patches / K-half exchange fit the ring");
-    __shared__ __align__(16) unsigned char lds[S * STAGE + (B_PAD ? 1024 : 0)];
+    // Per-stage operands of the K loop come from a TABLE in LDS, built once per K range: entry j (16 bytes) describes K-step
+    // kt_begin + j = {byte offset its filter tap and channel run add to a pixel's base address, byte offset of its k-groups in a
+    // row of the weight image, the tap's bit in the rows' validity masks, flags}.  The K loop is bound by the instructions its
+    // waves issue, scalar ones above all (measured on the 128x128, 32-k step: 1949 cycles with 69 scalar instructions per wave
+    // and phase, 2290 with 104, 1672 with the stage state frozen; the step's MFMAs take 1536), and keeping (step, tap, channel)
+    // counters, the tap's address offset and two descriptors up to date on the scalar unit cost ~45 of them; one broadcast
+    // ds_read_b128 per phase and a few vector operations on its result cost next to nothing (they issue in MFMA shadows).
+    // Tiles whose ring fills the LDS of two workgroups per CU keep the scalar form (TABLE false).
+    constexpr int TAB_N = kDmaTabEntries, TAB_BYTES = TAB_N * 16, TAB_OFF = S * STAGE + (B_PAD ? 1024 : 0);
+    constexpr int LB_WGS = (2 * S * dma_stage_bytes(BM, BK, 128 * WAVES_N) <= 160 * 1024) ? 2 : 1;
+    constexpr bool TABLE = LB_WGS * (TAB_OFF + TAB_BYTES) <= 160 * 1024;
+    __shared__ __align__(16) unsigned char lds[TAB_OFF + (TABLE ? TAB_BYTES : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WAVES_M, wk = (wave / WAVES_M) % WAVES_K, wn = wave / (WAVES_M * WAVES_K);
@@ -998,7 +1019,7 @@ conv_dma_kernel(const ConvParams p) {
     // rows' state in two named structs: an array of them ends up in scratch memory behind the source select below, and a
     // scratch access is a VMEM operation that would sit in the middle of the hand-counted vmcnt)
     static_assert(PA_W == 1 || PA_W == 2, "one or two A pieces per wave and stage");
-    struct ARow { unsigned base, base2; int ih0, iw0; };
+    struct ARow { unsigned base, base2; int ih0, iw0; unsigned mask; };   // mask: bit t = filter tap t lies inside the image for this row
     unsigned b_voff[P - PA_W], ldst[P];
     auto make_arow = [&](int i) {
         ARow ar;
@@ -1017,6 +1038,13 @@ conv_dma_kernel(const ConvParams p) {
         } else {
             ar.ih0 = INT_MIN / 2; ar.iw0 = INT_MIN / 2; ar.base = 0; ar.base2 = kOOB;
         }
+        ar.mask = 0;
+        if (TABLE && m < p.M) {
+            ar.mask = kDmaSecondBit;
+            for (int kh = 0, t = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw, ++t)
+                    if ((unsigned)(ar.ih0 + kh) < (unsigned)p.H && (unsigned)(ar.iw0 + kw) < (unsigned)p.W) ar.mask |= 1u << t;
+        }
         return ar;
     };
     const ARow ar0 = make_arow(0), ar1 = make_arow(PA_W - 1);
@@ -1034,75 +1062,105 @@ conv_dma_kernel(const ConvParams p) {
             ldst[i] = real ? A_BYTES + plane * B_PLANE + rb * 1024 : S * STAGE;
         }
         ldst[i] = __builtin_amdgcn_readfirstlane(ldst[i] + lds0);
+        asm volatile("" : "+s"(ldst[i]));                        // (opaque: dma16 adds a possibly literal slot offset to it in one s_add)
     }
     // State of the stage being ISSUED, all wave-uniform (scalar unit): its K-step, filter tap, channel base, the byte offset
     // that tap adds to a pixel's base address, which source it reads and the two descriptors (zero records once the stage lies
     // past this workgroup's K range: a null DMA, no memory traffic, zeros written, so that the counted waits never change).
     // Step order of the first source: (tap, channels) = the order of k in the weight image, or under p.cmajor (32-channel
     // block, tap, 16-channel half when BK == 16): the same steps in another sequence, so only which k-groups of the image a
-    // step fetches changes (u_woff below).
-    int u_kt = kt_begin, u_kh, u_kw, u_ci;
+    // step fetches changes (u_woff below).  ONE update serves both orders: a tap is done when the channel offset has run
+    // p.ci_wrap channels past the block base u_cb (ci_wrap = Cin with u_cb = 0: tap-major; 32 with u_cb moving on after the last
+    // tap: block-major).  The K loop is bound by the instructions its two waves per SIMD issue, not by the matrix pipe (one
+    // more scalar instruction per stage costs 8 cycles of a 1950-cycle step: measured 1949 -> 2290 cycles with 40 more), so this
+    // state is kept to plain scalar integer selects.
+#ifdef TSOD_DIAG_NODMA
+    const int nodma_steps = __builtin_amdgcn_readfirstlane(*(volatile int *)&g_nodma_steps);
+#endif
+    int u_kt = kt_begin, u_kh, u_kw, u_ci, u_cb;
     {
         constexpr int SUB = 32 / BK;
         const int blk = kt_begin / SUB, sub = kt_begin - blk * SUB, taps = p.KH * p.KW;
         const int cb = blk / taps, tap_c = blk - cb * taps;      // channel-block-major
         const int kb = kt_begin * BK, tap_t = kb / p.Cin;        // tap-major
         const int tap = p.cmajor ? tap_c : tap_t;
+        u_cb = p.cmajor ? cb * 32 : 0;
         u_ci = p.cmajor ? cb * 32 + sub * BK : kb - tap_t * p.Cin;
         u_kh = tap / p.KW;
         u_kw = tap - u_kh * p.KW;
     }
     unsigned u_delta, u_woff;
     bool u_second;
-    v4i32 u_rs_a, u_rs_w;
+    v4i32 u_rs_a = rs_in, u_rs_w = rs_w;
+    const int k1_steps = p.K1 / BK;                               // (K1 % BK == 0: tile_ok_for)
     auto stage_state = [&]() {
+#ifdef TSOD_DIAG_NODMA
+        const bool live = u_kt < kt_begin + nodma_steps;         // timing probe only (make nodma): null DMAs after the ring's first fill
+#else
         const bool live = u_kt < kt_end;
-        u_second = u_kt * BK >= p.K1;                             // second source: a 1x1 tap, always inside the image
-        u_delta = u_second ? (unsigned)((u_kt * BK - p.K1) * 4) : (unsigned)(((u_kh * p.W + u_kw) * p.in_pitch + u_ci) * 4);
-        u_woff = (p.cmajor && !u_second) ? (unsigned)((((u_kh * p.KW + u_kw) * p.Cin + u_ci) >> 3) * 48) : (unsigned)(u_kt * (BK / 8) * 48);
-        // (readfirstlane: the divergence analysis loses sight of the uniformity of this loop-carried state, and a descriptor
-        //  must sit in scalar registers)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            u_rs_a[c] = __builtin_amdgcn_readfirstlane(c == 2 && !live ? 0 : (u_second ? rs_in2[c] : rs_in[c]));
-            u_rs_w[c] = __builtin_amdgcn_readfirstlane(c == 2 && !live ? 0 : rs_w[c]);
-        }
-        u_delta = (unsigned)__builtin_amdgcn_readfirstlane((int)u_delta);
-        u_woff = (unsigned)__builtin_amdgcn_readfirstlane((int)u_woff);
+#endif
+        u_second = u_kt >= k1_steps;                              // second source: a 1x1 tap, always inside the image
+        const int d1 = ((u_kh * p.W + u_kw) * p.in_pitch + u_ci) * 4, d2 = (u_kt - k1_steps) * (BK * 4);
+        // byte offset of k in a row of the weight image = (k / 8) * 48 = 6 k (k % 8 == 0); first source k = tap * Cin + channel
+        const int w1 = ((u_kh * p.KW + u_kw) * p.Cin + u_ci) * 6, w2 = u_kt * (BK * 6);
+        u_delta = (unsigned)(u_second ? d2 : d1);
+        u_woff = (unsigned)(u_second ? w2 : w1);
+        u_rs_a[0] = u_second ? rs_in2[0] : rs_in[0];
+        u_rs_a[1] = u_second ? rs_in2[1] : rs_in[1];
+        u_rs_a[2] = live ? (u_second ? rs_in2[2] : rs_in[2]) : 0;
+        u_rs_w[2] = live ? rs_w[2] : 0;
     };
     stage_state();
     auto advance_stage = [&]() {
+#ifdef TSOD_DIAG_NOADVANCE
+        return;                                                  // timing probe only (make noadvance): every stage fetches the first one again
+#endif
         ++u_kt;
-        // (selects, not nested updates: written as branches these three scalars end up in scratch memory, and a scratch access
-        //  is a VMEM operation in the middle of the hand-counted vmcnt)
+        // (selects, not nested updates: written as branches these scalars end up in scratch memory, and a scratch access is a
+        //  VMEM operation in the middle of the hand-counted vmcnt)
         const int ci1 = u_ci + BK, kw1 = u_kw + 1, kh1 = u_kh + 1;
-        // tap-major: the tap is done when its channels are; channel-block-major: when this tap's 32-channel block is, and the
-        // block only moves on after the last tap
-        const bool tap_done = p.cmajor ? (ci1 & 31) == 0 : ci1 >= p.Cin;
-        const bool row_done = tap_done && kw1 == p.KW;
-        const bool all_taps = row_done && kh1 == p.KH;
-        u_ci = !tap_done ? ci1 : (p.cmajor ? (all_taps ? ci1 : ci1 - 32) : 0);
-        u_kw = !tap_done ? u_kw : (row_done ? 0 : kw1);
-        u_kh = !row_done ? u_kh : ((p.cmajor && all_taps) ? 0 : kh1);
+        const bool tap_done = ci1 - u_cb >= p.ci_wrap;
+        const bool row_done = tap_done & (kw1 == p.KW);
+        const bool all_taps = row_done & (kh1 == p.KH);
+        u_cb = all_taps ? u_cb + 32 : u_cb;
+        u_ci = tap_done ? u_cb : ci1;
+        u_kw = tap_done ? (row_done ? 0 : kw1) : u_kw;
+        u_kh = row_done ? (all_taps ? 0 : kh1) : u_kh;
         stage_state();
     };
     // piece I of the stage being issued into ring slot `slot` (branch-free: selects only; I is a compile-time constant so
     // that the per-piece state stays in registers)
-    auto issue_piece = [&](auto I, int slot) {
+    // What the table entry of the stage being issued says (TABLE; set at the top of a phase): the entry itself (vector
+    // registers, the same in every lane), the weight offset, which source, and the two descriptors
+    u32x4 t_e = {0u, 0u, 0u, 0u};
+    unsigned t_woff = 0;
+    bool t_second = false;
+    v4i32 t_rs_a = rs_in, t_rs_w = rs_w;
+    auto issue_piece = [&](auto I, auto FROM_TABLE, unsigned slot_off) {
         constexpr int i = decltype(I)::value;
+        constexpr bool from_table = decltype(FROM_TABLE)::value;
         if constexpr (i < PA_W) {
             const ARow ar = i == 0 ? ar0 : ar1;
-            const int ih = ar.ih0 + u_kh, iw = ar.iw0 + u_kw;
-            const bool ok1 = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            // (second source: rows >= M carry the out-of-range base, plus a delta it may wrap into the tensor: such rows read
-            //  real bytes instead of zeros, which is harmless - they feed output rows that are never stored)
-            const unsigned v1 = ok1 ? ar.base + u_delta : kOOB, v2 = ar.base2 + u_delta;
-            dma16(u_second ? v2 : v1, u_rs_a, 0u, ldst[i] + slot * STAGE);
+            if constexpr (from_table) {
+                // a row fetches when the stage's tap lies inside the image for it (rows past M and every row of a stage past the
+                // K range have no bit in common with the entry: the out-of-range offset, no memory traffic, zeros written)
+                const bool ok = (ar.mask & t_e.z) != 0;
+                const unsigned v = (t_second ? ar.base2 : ar.base) + t_e.x;
+                dma16(ok ? v : kOOB, t_rs_a, 0u, ldst[i], slot_off);
+            } else {
+                const int ih = ar.ih0 + u_kh, iw = ar.iw0 + u_kw;
+                const bool ok1 = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                // (second source: rows >= M carry the out-of-range base, plus a delta it may wrap into the tensor: such rows read
+                //  real bytes instead of zeros, which is harmless - they feed output rows that are never stored)
+                const unsigned v1 = ok1 ? ar.base + u_delta : kOOB, v2 = ar.base2 + u_delta;
+                dma16(u_second ? v2 : v1, u_rs_a, 0u, ldst[i], slot_off);
+            }
         } else {
             // (a padding piece has the out-of-range source everywhere; its destination is the scratch KiB behind the ring, which
             //  the slot offset must not move: ldst - lds0 == S * STAGE marks it)
-            const unsigned dst = (B_PAD && ldst[i] - lds0 == (unsigned)(S * STAGE)) ? ldst[i] : ldst[i] + slot * STAGE;
-            dma16<1>(b_voff[i - PA_W], u_rs_w, u_woff, dst);
+            const unsigned so = (B_PAD && ldst[i] - lds0 == (unsigned)(S * STAGE)) ? 0u : slot_off;
+            if constexpr (from_table) dma16<1>(b_voff[i - PA_W], t_rs_w, t_woff, ldst[i], so);
+            else dma16<1>(b_voff[i - PA_W], u_rs_w, u_woff, ldst[i], so);
         }
     };
 
@@ -1133,20 +1191,58 @@ conv_dma_kernel(const ConvParams p) {
     // first gaps (A raw first), its A fragment is split behind MFMAs 4..23 (one pair per five MFMAs: h = rne(x); x -= h;
     // m = rne(x); x -= m; l = rne(x); at most 3 VALU per MFMA gap, which is what issues in an MFMA's shadow), and this
     // wave's DMA pieces of the stage being issued go out one per few gaps.  `soff` = byte offset of the ring slot that is read.
+    // `tab_ptr` (TABLE): LDS address of the table entry of the stage this phase issues; it moves on by one entry per phase
+    unsigned tab_ptr = lds0 + TAB_OFF + S * 16;
     auto phase = [&](const Frags &cur, Frags &nxt, unsigned soff, int dma_slot) {
         float4 raw0, raw1;
         unsigned hh[4], mm[4], ll[4];
         float t0, t1, r0, r1, q0, q1;
-#define TSOD_DMA(I) do { if constexpr ((I) < P) issue_piece(std::integral_constant<int, (I)>{}, dma_slot); } while (0)
+        const unsigned slot_off = (unsigned)(dma_slot * STAGE);
+#define TSOD_DMA(I) do { if constexpr ((I) < P) issue_piece(std::integral_constant<int, (I)>{}, std::integral_constant<bool, TABLE>{}, slot_off); } while (0)
 #define TSOD_MF(n) acc[0][(n) & 3], cur.a[PA[(n) >> 2]], cur.b[(n) & 3][PB[(n) >> 2]]
+        if constexpr (TABLE) {
+            lds_read16<0>(t_e, tab_ptr);                         // oldest of this phase's LDS reads
+            tab_ptr += 16;
+        }
         lds_read16<0>(raw0, a_addr[0] + soff);
         lds_read16<0>(raw1, a_addr[1] + soff);
         gap_read<0 * B_PLANE>(TSOD_MF(0), nxt.b[0][0], b_addr[0] + soff);
         gap_read<0 * B_PLANE>(TSOD_MF(1), nxt.b[1][0], b_addr[1] + soff);
         gap_read<0 * B_PLANE>(TSOD_MF(2), nxt.b[2][0], b_addr[2] + soff);
         gap_read<0 * B_PLANE>(TSOD_MF(3), nxt.b[3][0], b_addr[3] + soff);
-        TSOD_DMA(0);
-        wait_lgkm<4>();                                         // raw0, raw1 have landed (four younger reads may be out)
+        if constexpr (TABLE) {
+            wait_lgkm_for<4>(t_e);                               // the entry, raw0, raw1 have landed (four younger reads may be out)
+            const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)t_e.w);
+            t_woff = (unsigned)__builtin_amdgcn_readfirstlane((int)t_e.y);
+            t_second = (flags & 1u) != 0;
+            // (readfirstlane: the divergence analysis loses sight of the uniformity of this state, and a descriptor must sit
+            //  in scalar registers; on values that are scalar already it folds away)
+            t_rs_w[0] = __builtin_amdgcn_readfirstlane(rs_w[0]);
+            t_rs_w[1] = __builtin_amdgcn_readfirstlane(rs_w[1]);
+            t_rs_w[2] = __builtin_amdgcn_readfirstlane((flags & 2u) ? 0 : rs_w[2]);   // a stage past the K range: null weight DMAs as well
+            t_rs_w[3] = __builtin_amdgcn_readfirstlane(rs_w[3]);
+            t_rs_a[0] = __builtin_amdgcn_readfirstlane(t_second ? rs_in2[0] : rs_in[0]);
+            t_rs_a[1] = __builtin_amdgcn_readfirstlane(t_second ? rs_in2[1] : rs_in[1]);
+            t_rs_a[2] = __builtin_amdgcn_readfirstlane(t_second ? rs_in2[2] : rs_in[2]);
+            t_rs_a[3] = __builtin_amdgcn_readfirstlane(rs_in[3]);
+            TSOD_DMA(0);
+        } else {
+            TSOD_DMA(0);
+            wait_lgkm<4>();                                     // raw0, raw1 have landed (four younger reads may be out)
+        }
+#ifdef TSOD_DIAG_NOSPLIT
+        // timing probe only (make nosplit; wrong results by design): the same MFMAs, LDS reads and DMAs without the VALU work of
+        // the activation split - what a K loop fed with PRE-SPLIT activations could reach
+#define TSOD_SPLIT_GROUP(N0, X0, X1, G, PL, J0, J1)                                                        \
+        mfma_bf16(TSOD_MF(N0));                                                                            \
+        gap_read<PL * B_PLANE>(TSOD_MF(N0 + 1), nxt.b[J0][PL], b_addr[J0] + soff);                         \
+        mfma_bf16(TSOD_MF(N0 + 2));                                                                        \
+        if constexpr (P > 5) TSOD_DMA(1 + 2 * G);                                                          \
+        gap_read<PL * B_PLANE>(TSOD_MF(N0 + 3), nxt.b[J1][PL], b_addr[J1] + soff);                         \
+        mfma_bf16(TSOD_MF(N0 + 4));                                                                        \
+        hh[G] = __float_as_uint(X0) & 0x3f803f80u; mm[G] = __float_as_uint(X1) & 0x3f803f80u; ll[G] = hh[G];   \
+        if constexpr (P > 5) TSOD_DMA(2 + 2 * G); else TSOD_DMA(1 + G);
+#else
 #define TSOD_SPLIT_GROUP(N0, X0, X1, G, PL, J0, J1)                                                        \
         gap_cvt(TSOD_MF(N0), X0, X1, hh[G], t0, t1);                                                       \
         gap_sub<PL * B_PLANE>(TSOD_MF(N0 + 1), r0, r1, X0, X1, t0, t1, nxt.b[J0][PL], b_addr[J0] + soff);  \
@@ -1155,6 +1251,7 @@ conv_dma_kernel(const ConvParams p) {
         gap_sub<PL * B_PLANE>(TSOD_MF(N0 + 3), q0, q1, r0, r1, t0, t1, nxt.b[J1][PL], b_addr[J1] + soff);  \
         gap_last(TSOD_MF(N0 + 4), q0, q1, ll[G]);                                                          \
         if constexpr (P > 5) TSOD_DMA(2 + 2 * G); else TSOD_DMA(1 + G);
+#endif
         TSOD_SPLIT_GROUP(4, raw0.x, raw0.y, 0, 2, 0, 1)
         TSOD_SPLIT_GROUP(9, raw0.z, raw0.w, 1, 2, 2, 3)
         TSOD_SPLIT_GROUP(14, raw1.x, raw1.y, 2, 1, 0, 1)
@@ -1162,7 +1259,7 @@ conv_dma_kernel(const ConvParams p) {
 #undef TSOD_MF
 #undef TSOD_SPLIT_GROUP
         static_assert(P <= 9, "DMA slots of a phase");
-        advance_stage();
+        if constexpr (!TABLE) advance_stage();
         nxt.a[0] = __builtin_bit_cast(bf16x8, (u32x4{hh[0], hh[1], hh[2], hh[3]}));
         nxt.a[1] = __builtin_bit_cast(bf16x8, (u32x4{mm[0], mm[1], mm[2], mm[3]}));
         nxt.a[2] = __builtin_bit_cast(bf16x8, (u32x4{ll[0], ll[1], ll[2], ll[3]}));
@@ -1178,11 +1275,50 @@ conv_dma_kernel(const ConvParams p) {
 #endif
     if (nk > 0) {
         // prologue: every ring slot filled (stages kt_begin .. kt_begin + S - 1), stage 0 visible, its fragments in X
+#undef TSOD_DMA
+#define TSOD_DMA(I) do { if constexpr ((I) < P) issue_piece(std::integral_constant<int, (I)>{}, std::false_type{}, slot_off); } while (0)
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const int dma_slot = s;
+            const unsigned slot_off = (unsigned)(s * STAGE);
             TSOD_DMA(0); TSOD_DMA(1); TSOD_DMA(2); TSOD_DMA(3); TSOD_DMA(4); TSOD_DMA(5); TSOD_DMA(6); TSOD_DMA(7); TSOD_DMA(8);
             advance_stage();
+        }
+        // the stage table of this K range (entries 0 .. nk + S: the loop issues stages S .. nk - 1 + S, one more when nk is odd;
+        // built while the prologue's DMAs are in flight, visible to every wave behind the barrier that ends the prologue)
+        if constexpr (TABLE) {
+            constexpr int SUB = 32 / BK;
+            const int taps = p.KH * p.KW;
+            for (int j = tid; j <= nk + S; j += THREADS) {
+#if defined(TSOD_DIAG_NOADVANCE)
+                const int step = kt_begin;
+#else
+                const int step = kt_begin + j;
+#endif
+#if defined(TSOD_DIAG_NODMA)
+                const bool live = j < nodma_steps;
+#else
+                const bool live = step < kt_end;
+#endif
+                u32x4 e = {0u, 0u, 0u, 2u};                       // dead: no row fetches, null weight descriptor
+                if (live) {
+                    if (step >= k1_steps) {
+                        e = {(unsigned)((step - k1_steps) * (BK * 4)), (unsigned)(step * (BK * 6)), kDmaSecondBit, 1u};
+                    } else {
+                        int tap, ci;
+                        if (p.cmajor) {
+                            const int blk = step / SUB, cb = blk / taps;
+                            tap = blk - cb * taps;
+                            ci = cb * 32 + (step - blk * SUB) * BK;
+                        } else {
+                            tap = step * BK / p.Cin;
+                            ci = step * BK - tap * p.Cin;
+                        }
+                        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+                        e = {(unsigned)(((kh * p.W + kw) * p.in_pitch + ci) * 4), (unsigned)((tap * p.Cin + ci) * 6), 1u << tap, 0u};
+                    }
+                }
+                *reinterpret_cast<u32x4 *>(lds + TAB_OFF + j * 16) = e;
+            }
         }
         wait_vm<(S - 1) * P>();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1403,7 +1539,8 @@ int desc_k(const tsod_conv2d_desc *d) { return d->KH * d->KW * desc_cin(d) + (d-
 bool tile_ok_for(const tsod_conv2d_desc *d, int tile) {
     const int bk = kTiles[tile].bk;
     if (kTiles[tile].dma)
-        return d->n_seg == 1 && desc_cin(d) % bk == 0 && (d->c2 <= 0 || d->c2 % bk == 0);
+        return d->n_seg == 1 && desc_cin(d) % bk == 0 && (d->c2 <= 0 || d->c2 % bk == 0) &&
+               d->KH * d->KW <= 31 && desc_k(d) / bk + 8 <= kDmaTabEntries;   // (the stage table: one mask bit per tap, K range + ring)
     if (d->c2 <= 0) return true;
     return desc_cin(d) % bk == 0 && (d->KH * d->KW * desc_cin(d)) % bk == 0 && d->c2 % bk == 0;
 }
@@ -1667,6 +1804,7 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
     p.dp_tiles = sc.dp_tiles; p.split = sc.split; p.ksteps_per_split = sc.ksteps_per_split; p.sk_q = sc.sk_q;
     p.nmajor = sc.nmajor;
     p.cmajor = (kTiles[sc.tile].dma && d->KH * d->KW > 1 && p.Cin % 32 == 0 && kstep_order_override() != 0) ? 1 : 0;
+    p.ci_wrap = p.cmajor ? 32 : p.Cin;
     if (sc.rem_tiles > 0)
         TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= sc.ws_bytes && tsod_aligned16(workspace), TSOD_ERR_WORKSPACE);
     p.tickets = static_cast<int *>(workspace);
