@@ -10,6 +10,8 @@ Data layout in HBM: every activation is NHWC f32, channel pitch a multiple of 4,
 """
 from __future__ import annotations
 
+import re
+
 from collections import OrderedDict
 from ctypes import byref, c_int32
 from typing import Callable, Sequence
@@ -348,13 +350,29 @@ class Plan:
             # second look at the few fastest with four times the repetitions: at 25-50 us per launch a 3-repetition sample
             # is noisy enough to pick a 3-5 % slower schedule now and then
             timed.sort()
-            best = None
+            best, second_look = None, []
             for t0, tile, split, prec in timed[:4]:
                 t = time_candidate(tile, split, prec, 4 * reps) if len(timed) > 1 else t0
-                if t is not None and (best is None or t < best[0]):
-                    best = (t, tile, split, prec)
+                if t is not None:
+                    second_look.append((t, tile, split, prec))
+                    if best is None or t < best[0]:
+                        best = (t, tile, split, prec)
             if best is None:
                 raise TsodError(f"autotune: no runnable (tile, split) candidate for {st.name}")
+            # a tie on the clock (within 2 %) goes to the candidate that moves fewer bytes beyond the L2s: the K-slice slabs
+            # (written and read back) plus the weights, which every XCD fetches for itself under the uniform schedules and every
+            # WORKGROUP under the balanced one (its workgroups walk K out of step, so a weight block is in nobody else's L2 when
+            # it is wanted: measured 1.4 GB for a 14 MB layer4 3x3 at batch 8, 2 % faster than the hybrid schedule's 0.28 GB)
+            def beyond_l2(tile, split, prec):
+                st.choose(tile, split, prec)
+                slabs = max(0, int(lib().tsod_conv2d_workspace_bytes(byref(d))) - (256 << 10))
+                wbytes = d.Cout * K * (6 if prec == _ffi.PREC_BF16X3 else 4)
+                m = re.search(r"(\d+)x(\d+)", TILE_NAMES[tile])
+                tiles_m = -(-M // int(m.group(1))) if m else 8
+                return 2 * slabs + wbytes * (tiles_m if split == -2 else 8)
+            close = [c for c in second_look if c[0] <= best[0] * 1.02]
+            if len(close) > 1:
+                best = min(close, key=lambda c: (beyond_l2(c[1], c[2], c[3]), c[0]))
             st.choose(best[1], best[2], best[3])
             shortlist.append([(tile, split, prec) for _, tile, split, prec in timed[:max(1, int(in_sequence), int(keep_shortlist))]])
             results.append((st.name, best[0], best[1], best[2], st.flops, best[3]))
