@@ -575,6 +575,31 @@ def test_conv_dual_source_is_the_sum_of_two_convs(ops, dev, C1, C2, Cout, stride
         _ffi.check(_ffi.lib().tsod_conv2d_f32(byref(d), _ffi.ptr(yn), _ffi.ptr(w), None, None, None, _ffi.ptr(out), None, 0, None))
 
 
+def test_conv_dma_tiles_stage_table_limits_and_step_order(ops, dev):
+    """The LDS-DMA tiles keep one table entry per K-step of a workgroup's K range (640 entries): a K that needs more steps than
+    that at a tile's stage size is REFUSED for that tile when named and never picked by TSOD_TILE_AUTO, while the tiles with
+    longer stages still take it.  Same layer: a 3x3 filter on these tiles runs its K-steps in (channel block, tap) order -
+    whole tiles, uniform K-slices (slices = channel-block ranges) and the balanced ranges must all match the f64 convolution."""
+    from two_stage_object_detection_amd._ffi import TsodError
+    g = torch.Generator().manual_seed(77)
+    Cin, Cout, H, W = 1280, 128, 9, 11                                       # K = 11520: 720 steps of 16, 360 of 32
+    x = torch.randn(1, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    ref = F.conv2d(x.double(), w.double(), padding=1).float()
+    xn = ops.nchw_to_nhwc(x.to(dev))
+    wp = ops.pack_conv_weight(w.to(dev))
+    tol = 3e-6 * math.sqrt(9 * Cin) + 1e-5
+    for tile in (17, 19, 21):                                                # 16-float stages: 720 + 8 > 640
+        with pytest.raises(TsodError, match="unsupported|UNSUPPORTED"):
+            ops.conv2d_nhwc(xn, wp, pad=1, tile=tile, split_k=1, precision=1)
+    for tile in (18, 20, 22):                                                # 32-float stages: 360 + 8 entries
+        for split in (1, 3, -1, -2):
+            out = ops.conv2d_nhwc(xn, wp, pad=1, tile=tile, split_k=split, precision=1)
+            assert (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item() <= tol, (tile, split)
+    out = ops.conv2d_nhwc(xn, wp, pad=1, precision=1)                        # AUTO resolves to something that runs
+    assert (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item() <= tol
+
+
 @pytest.mark.parametrize("C1,C2", [(64, 48), (64, 32), (32, 96)])
 def test_conv_dual_source_second_source_must_be_whole_ksteps(ops, dev, C1, C2):
     """The stacked-K GEMM's K-steps must not run past the second source's c2 channels (the uniform-tap loader has no k < K
