@@ -73,7 +73,10 @@ enum { TSOD_TILE_AUTO = 0, TSOD_TILE_128x128 = 1, TSOD_TILE_128x64 = 2, TSOD_TIL
        TSOD_TILE_128x64_W8_S1 = 9, TSOD_TILE_64x64_S1_K64 = 10, TSOD_TILE_128x64_W8_S1_K64 = 11,
        TSOD_TILE_64x64_W1_S1 = 12, TSOD_TILE_128x64_W2_S1 = 13, TSOD_TILE_128x64_S1 = 14, TSOD_TILE_64x128_S1 = 15,
        TSOD_TILE_128x128_S1 = 16,
-       /* bf16x3 only, fed by LDS-DMA (conv_dma_kernel): one channel segment, Cin a multiple of the K stage (16 / 32) */
+       /* bf16x3 only, fed by LDS-DMA (conv_dma_kernel): one channel segment, Cin a multiple of the K stage (16 / 32 floats),
+        * KH * KW <= 31 and K / stage + 8 <= 640 (one table entry per K-step of a workgroup's K range); anything else is
+        * TSOD_ERR_UNSUPPORTED for these tiles (TSOD_TILE_AUTO then resolves to another tile).  Filters with more than one tap
+        * run their K-steps in (32-channel block, tap) order: another f32 summation order than the other tiles, same weights */
        TSOD_TILE_D128x128 = 17, TSOD_TILE_D64x128 = 18, TSOD_TILE_D256x128 = 19,
        TSOD_TILE_D64x128_S2 = 20 /* two ring stages: two workgroups per CU */,
        TSOD_TILE_D128x256 = 21 /* two columns of waves share the activation stage */,
