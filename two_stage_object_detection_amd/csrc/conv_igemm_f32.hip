@@ -188,6 +188,11 @@ struct SliceMap {
     }
 };
 
+#ifdef TSOD_CLOCK_DIAG
+// diagnostic build: s_memtime stamps of thread 0 inside a K-slice's epilogue, 8 int64 per workgroup (scripts/dma_timeline.py):
+//   [0] entry  [1] slab stores drained  [2] ticket add returned  [3] other slices' slabs + residual in registers  [4] exit  [5] 1 = last arriver
+__device__ long long *g_epi_stamps = nullptr;
+#endif
 // G = slabs of OTHER slices a combining thread keeps in flight at once (registers: G * 32 on top of the running sums)
 template <int BM, int BN, int WM, int WN, int THREADS, int G = 1>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[WM / 32][WN / 32], float *smem, int tid, int wm, int wn,
@@ -235,6 +240,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
         //       protects plain loads - there are none.
         // The atomic itself is relaxed: ordering against the slab stores comes from (3), not from the atomic's semantics.
         constexpr int AUX_SC1 = 16;
+#ifdef TSOD_CLOCK_DIAG
+        long long *const eo = (g_epi_stamps != nullptr && tid == 0 && blockIdx.x < 8192) ? g_epi_stamps + 8 * (long)blockIdx.x : nullptr;
+        if (eo) eo[0] = __builtin_amdgcn_s_memtime();
+#endif
         const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc((void *)p.partial, (short)0, (int)p.part_bytes, 0x00020000);
         const int rem = sm.ticket;
         const unsigned my_slab = sm.slab(z) * (unsigned)(BM * BN * 4);                       // byte offset of this slice's slab
@@ -261,6 +270,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // EVERY storing wave drains its write-through stores
+#ifdef TSOD_CLOCK_DIAG
+        if (eo) eo[1] = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
         int *s_flag = reinterpret_cast<int *>(smem);                       // the one LDS array (patches are idle past the barrier)
         if (tid == 0) {
@@ -268,6 +280,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
             const int last = old == sm.count - 1;
             if (last) __hip_atomic_store(p.tickets + rem, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every slice has arrived
             s_flag[0] = last;
+#ifdef TSOD_CLOCK_DIAG
+            if (eo) { eo[2] = __builtin_amdgcn_s_memtime(); eo[5] = last; }
+#endif
         }
         __syncthreads();
         if (s_flag[0] == 0) return;
@@ -294,6 +309,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
                 qoff[u] = (unsigned)q * 16u;
                 mq[u] = m0 + q / QPR;
                 nq[u] = n0 + (q % QPR) * 4;
+            }
+            // (THREADS is a multiple of the quads per row, so all of a thread's quads sit in ONE column group: its BN scale / shift
+            //  are one pair of loads, issued HERE with the residual and the slabs - inside the store loop below they were a
+            //  dependent round trip between the last slab and the first store of the launch's critical path)
+            static_assert(THREADS % QPR == 0, "a thread's quads share their output channels");
+            float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.vec_epilogue && nq[0] < p.Cout) {
+                if (p.scale) sc4 = *reinterpret_cast<const float4 *>(p.scale + nq[0]);
+                if (p.shift) sh4 = *reinterpret_cast<const float4 *>(p.shift + nq[0]);
             }
             if (p.vec_epilogue) {                                          // the residual rides along with the first group of slices
 #pragma unroll
@@ -328,15 +352,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
                     }
                 }
             }
+#ifdef TSOD_CLOCK_DIAG
+            if (eo) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); eo[3] = __builtin_amdgcn_s_memtime(); }
+#endif
 #pragma unroll
             for (int u = 0; u < QB; ++u) {
                 const int m = mq[u], n = nq[u];
                 if (m >= p.M || n >= p.Cout) continue;
                 float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
                 if (p.vec_epilogue) {                                      // Cout % 4 == 0: all four channels exist
-                    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + n);
-                    if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + n);
+                    const float4 sc = sc4, sh = sh4;
                     u32x4 o;
                     o.x = __float_as_uint(apply_act(vv[0] * sc.x + sh.x + rs4[u].x, p.neg_slope, p.act_hi));
                     o.y = __float_as_uint(apply_act(vv[1] * sc.y + sh.y + rs4[u].y, p.neg_slope, p.act_hi));
@@ -354,6 +379,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
                 }
             }
         }
+#ifdef TSOD_CLOCK_DIAG
+        if (eo) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); eo[4] = __builtin_amdgcn_s_memtime(); }
+#endif
         return;
     }
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, (short)0, (int)p.out_bytes, 0x00020000);
@@ -839,7 +867,8 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     }
 #endif
     const SliceMap sm = {z, p.split, tile_id - p.dp_tiles, -1, 0, 0};
-    conv_epilogue<BM, BN, WM, WN, THREADS>(p, acc, smem, tid, wm, wn, m0, n0, sm);
+    // (two slices' slabs in flight per round trip of the combine where a thread holds few quads: 64x64 tiles; one elsewhere - registers)
+    conv_epilogue<BM, BN, WM, WN, THREADS, (BM * BN / 4 / THREADS <= 4) ? 2 : 1>(p, acc, smem, tid, wm, wn, m0, n0, sm);
 }
 
 // =====================================================================================================================
@@ -1406,9 +1435,9 @@ conv_dma_kernel(const ConvParams p) {
                 for (int e = 0; e < 16; ++e) acc2[0][b][e] = smem[((partner * 2 + b) * 16 + e) * 64 + lane] + acc[0][2 + b][e];
         }
         __syncthreads();
-        conv_epilogue<BM, BN, 32, 64, THREADS, 3>(pe, acc2, smem, tid, wm, wk, m0, n0, sm);
+        conv_epilogue<BM, BN, 32, 64, THREADS, BALANCED ? 3 : 4>(pe, acc2, smem, tid, wm, wk, m0, n0, sm);
     } else {
-        conv_epilogue<BM, BN, 32, 128, THREADS, 3>(pe, acc, smem, tid, wm, wn, m0, n0, sm);
+        conv_epilogue<BM, BN, 32, 128, THREADS, BALANCED ? 3 : 4>(pe, acc, smem, tid, wm, wn, m0, n0, sm);
     }
 #ifdef TSOD_CLOCK_DIAG
     if (dg_on) {
@@ -1904,5 +1933,8 @@ extern "C" int tsod_debug_set_clock_buf(long long *buf /* device, 2 * 32768 int6
 }
 extern "C" int tsod_debug_set_dma_stamps(long long *buf /* device, 8 * 8192 int64, or NULL */) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_dma_stamps), &buf, sizeof(buf)) == hipSuccess ? TSOD_OK : TSOD_ERR_LAUNCH;
+}
+extern "C" int tsod_debug_set_epi_stamps(long long *buf /* device, 8 * 8192 int64, or NULL */) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_epi_stamps), &buf, sizeof(buf)) == hipSuccess ? TSOD_OK : TSOD_ERR_LAUNCH;
 }
 #endif
