@@ -959,6 +959,38 @@ __device__ __forceinline__ void gap_read(f32x16 &c, const bf16x8 &a, const bf16x
                  : "+v"(c), "=&v"(rd) : "v"(a), "v"(b), "v"(addr), "n"(OFF) : "memory");
 }
 
+#ifdef TSOD_DIAG_MFMA16
+// timing probe only (make mfma16; wrong results by design): every v_mfma_f32_32x32x16_bf16 of the K loop replaced by TWO
+// v_mfma_f32_16x16x32_bf16 on the same operand registers (the same matrix-pipe cycles and FLOPs, the other shape's register
+// traffic and power), everything else of the loop - DMAs, LDS reads, the activation split - unchanged
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+struct Acc16 { f32x4p lo, hi; };
+__device__ __forceinline__ void mfma_bf16(Acc16 &c, const bf16x8 &a, const bf16x8 &b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %2, %3, %1" : "+v"(c.lo), "+v"(c.hi) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void gap_cvt(Acc16 &c, const bf16x8 &a, const bf16x8 &b, float x0, float x1, unsigned &pk, float &t0, float &t1) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %5, %6, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %6, %1\n\t"
+                 "v_cvt_pk_bf16_f32 %2, %7, %8\n\tv_lshlrev_b32 %3, 16, %2\n\tv_and_b32 %4, 0xffff0000, %2"
+                 : "+v"(c.lo), "+v"(c.hi), "=&v"(pk), "=&v"(t0), "=&v"(t1) : "v"(a), "v"(b), "v"(x0), "v"(x1));
+}
+template <int OFF, typename T>
+__device__ __forceinline__ void gap_sub(Acc16 &c, const bf16x8 &a, const bf16x8 &b, float &r0, float &r1, float x0, float x1, float t0, float t1,
+                                        T &rd, unsigned addr) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %5, %6, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %6, %1\n\t"
+                 "v_sub_f32 %2, %7, %9\n\tv_sub_f32 %3, %8, %10\n\tds_read_b128 %4, %11 offset:%12"
+                 : "+v"(c.lo), "+v"(c.hi), "=&v"(r0), "=&v"(r1), "=&v"(rd) : "v"(a), "v"(b), "v"(x0), "v"(x1), "v"(t0), "v"(t1), "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void gap_last(Acc16 &c, const bf16x8 &a, const bf16x8 &b, float x0, float x1, unsigned &pk) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %4, %1\n\tv_cvt_pk_bf16_f32 %2, %5, %6"
+                 : "+v"(c.lo), "+v"(c.hi), "=&v"(pk) : "v"(a), "v"(b), "v"(x0), "v"(x1));
+}
+template <int OFF, typename T>
+__device__ __forceinline__ void gap_read(Acc16 &c, const bf16x8 &a, const bf16x8 &b, T &rd, unsigned addr) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %4, %1\n\tds_read_b128 %2, %5 offset:%6"
+                 : "+v"(c.lo), "+v"(c.hi), "=&v"(rd) : "v"(a), "v"(b), "v"(addr), "n"(OFF) : "memory");
+}
+#endif
+
 constexpr int dma_stage_bytes(int bm, int bk, int bn = 128) { return bm * bk * 4 + 3 * bn * bk * 2; }
 constexpr int kDmaTabEntries = 640;   // K-steps of one workgroup's K range + ring depth + 1 (tile_ok_for keeps K / bk + 8 below it)
 constexpr unsigned kDmaSecondBit = 0x80000000u;   // validity-mask bit of the second source's 1x1 tap (filter taps use bits 0..30)
@@ -1194,10 +1226,16 @@ conv_dma_kernel(const ConvParams p) {
     };
 
     f32x16 acc[1][TN];
+#ifdef TSOD_DIAG_MFMA16
+    Acc16 pacc[TN];                                               // the probe's accumulators (acc is zeroed behind the loop instead)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) pacc[j].lo = pacc[j].hi = f32x4p{0.f, 0.f, 0.f, 0.f};
+#else
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
+#endif
 
     // fragment addresses inside a stage: lane (h, r) holds k = 16 wk + 8 h .. + 7 of row r
     const int h = lane >> 5, r = lane & 31;
@@ -1228,7 +1266,11 @@ conv_dma_kernel(const ConvParams p) {
         float t0, t1, r0, r1, q0, q1;
         const unsigned slot_off = (unsigned)(dma_slot * STAGE);
 #define TSOD_DMA(I) do { if constexpr ((I) < P) issue_piece(std::integral_constant<int, (I)>{}, std::integral_constant<bool, TABLE>{}, slot_off); } while (0)
+#ifdef TSOD_DIAG_MFMA16
+#define TSOD_MF(n) pacc[(n) & 3], cur.a[PA[(n) >> 2]], cur.b[(n) & 3][PB[(n) >> 2]]
+#else
 #define TSOD_MF(n) acc[0][(n) & 3], cur.a[PA[(n) >> 2]], cur.b[(n) & 3][PB[(n) >> 2]]
+#endif
         if constexpr (TABLE) {
             lds_read16<0>(t_e, tab_ptr);                         // oldest of this phase's LDS reads
             tab_ptr += 16;
@@ -1397,6 +1439,12 @@ conv_dma_kernel(const ConvParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // asm-issued MFMA results -> ordinary reads
     }
 #undef TSOD_DMA
+#ifdef TSOD_DIAG_MFMA16
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][j][e] = pacc[j].lo[e & 3] + pacc[j].hi[e & 3];
+#endif
     __syncthreads();                                             // no wave reads the ring any more: the epilogue may use it
 #ifdef TSOD_CLOCK_DIAG
     if (dg_on) { const long long c = __builtin_amdgcn_s_memtime(); dg_loop += c - dg_c; dg_c = c; }
