@@ -931,32 +931,53 @@ __device__ __forceinline__ void mfma_bf16(f32x16 &c, const bf16x8 &a, const bf16
 //   gap_cvt:  MFMA; pk = rne_bf16x2(x0, x1); t0 = f32(pk.lo); t1 = f32(pk.hi)
 //   gap_sub:  MFMA; r0 = x0 - t0; r1 = x1 - t1 (exact); one LDS fragment read of the next stage
 //   gap_last: MFMA; pk = rne_bf16x2(x0, x1)
+// (DO = false only in the `make halfmfma` timing probe: the statement without its MFMA)
+template <bool DO = true>
 __device__ __forceinline__ void gap_cvt(f32x16 &c, const bf16x8 &a, const bf16x8 &b, float x0, float x1, unsigned &pk, float &t0, float &t1) {
+    if constexpr (DO)
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\t"
                  "v_cvt_pk_bf16_f32 %1, %6, %7\n\t"
                  "v_lshlrev_b32 %2, 16, %1\n\t"
                  "v_and_b32 %3, 0xffff0000, %1"
                  : "+v"(c), "=&v"(pk), "=&v"(t0), "=&v"(t1) : "v"(a), "v"(b), "v"(x0), "v"(x1));
+    else
+    asm volatile("v_cvt_pk_bf16_f32 %1, %6, %7\n\t"
+                 "v_lshlrev_b32 %2, 16, %1\n\t"
+                 "v_and_b32 %3, 0xffff0000, %1"
+                 : "+v"(c), "=&v"(pk), "=&v"(t0), "=&v"(t1) : "v"(a), "v"(b), "v"(x0), "v"(x1));
 }
-template <int OFF, typename T>
+template <int OFF, bool DO = true, typename T>
 __device__ __forceinline__ void gap_sub(f32x16 &c, const bf16x8 &a, const bf16x8 &b, float &r0, float &r1, float x0, float x1, float t0, float t1,
                                         T &rd, unsigned addr) {
+    if constexpr (DO)
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\t"
                  "v_sub_f32 %1, %6, %8\n\t"
                  "v_sub_f32 %2, %7, %9\n\t"
                  "ds_read_b128 %3, %10 offset:%11"
                  : "+v"(c), "=&v"(r0), "=&v"(r1), "=&v"(rd) : "v"(a), "v"(b), "v"(x0), "v"(x1), "v"(t0), "v"(t1), "v"(addr), "n"(OFF) : "memory");
+    else
+    asm volatile("v_sub_f32 %1, %6, %8\n\t"
+                 "v_sub_f32 %2, %7, %9\n\t"
+                 "ds_read_b128 %3, %10 offset:%11"
+                 : "+v"(c), "=&v"(r0), "=&v"(r1), "=&v"(rd) : "v"(a), "v"(b), "v"(x0), "v"(x1), "v"(t0), "v"(t1), "v"(addr), "n"(OFF) : "memory");
 }
+template <bool DO = true>
 __device__ __forceinline__ void gap_last(f32x16 &c, const bf16x8 &a, const bf16x8 &b, float x0, float x1, unsigned &pk) {
+    if constexpr (DO)
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\t"
                  "v_cvt_pk_bf16_f32 %1, %4, %5"
                  : "+v"(c), "=&v"(pk) : "v"(a), "v"(b), "v"(x0), "v"(x1));
+    else
+    asm volatile("v_cvt_pk_bf16_f32 %1, %4, %5" : "+v"(c), "=&v"(pk) : "v"(a), "v"(b), "v"(x0), "v"(x1));
 }
-template <int OFF, typename T>
+template <int OFF, bool DO = true, typename T>
 __device__ __forceinline__ void gap_read(f32x16 &c, const bf16x8 &a, const bf16x8 &b, T &rd, unsigned addr) {
+    if constexpr (DO)
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\t"
                  "ds_read_b128 %1, %4 offset:%5"
                  : "+v"(c), "=&v"(rd) : "v"(a), "v"(b), "v"(addr), "n"(OFF) : "memory");
+    else
+    asm volatile("ds_read_b128 %1, %4 offset:%5" : "+v"(c), "=&v"(rd) : "v"(a), "v"(b), "v"(addr), "n"(OFF) : "memory");
 }
 
 #ifdef TSOD_DIAG_MFMA16
@@ -968,23 +989,25 @@ struct Acc16 { f32x4p lo, hi; };
 __device__ __forceinline__ void mfma_bf16(Acc16 &c, const bf16x8 &a, const bf16x8 &b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %2, %3, %1" : "+v"(c.lo), "+v"(c.hi) : "v"(a), "v"(b));
 }
+template <bool DO = true>
 __device__ __forceinline__ void gap_cvt(Acc16 &c, const bf16x8 &a, const bf16x8 &b, float x0, float x1, unsigned &pk, float &t0, float &t1) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %5, %6, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %6, %1\n\t"
                  "v_cvt_pk_bf16_f32 %2, %7, %8\n\tv_lshlrev_b32 %3, 16, %2\n\tv_and_b32 %4, 0xffff0000, %2"
                  : "+v"(c.lo), "+v"(c.hi), "=&v"(pk), "=&v"(t0), "=&v"(t1) : "v"(a), "v"(b), "v"(x0), "v"(x1));
 }
-template <int OFF, typename T>
+template <int OFF, bool DO = true, typename T>
 __device__ __forceinline__ void gap_sub(Acc16 &c, const bf16x8 &a, const bf16x8 &b, float &r0, float &r1, float x0, float x1, float t0, float t1,
                                         T &rd, unsigned addr) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %5, %6, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %6, %1\n\t"
                  "v_sub_f32 %2, %7, %9\n\tv_sub_f32 %3, %8, %10\n\tds_read_b128 %4, %11 offset:%12"
                  : "+v"(c.lo), "+v"(c.hi), "=&v"(r0), "=&v"(r1), "=&v"(rd) : "v"(a), "v"(b), "v"(x0), "v"(x1), "v"(t0), "v"(t1), "v"(addr), "n"(OFF) : "memory");
 }
+template <bool DO = true>
 __device__ __forceinline__ void gap_last(Acc16 &c, const bf16x8 &a, const bf16x8 &b, float x0, float x1, unsigned &pk) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %4, %1\n\tv_cvt_pk_bf16_f32 %2, %5, %6"
                  : "+v"(c.lo), "+v"(c.hi), "=&v"(pk) : "v"(a), "v"(b), "v"(x0), "v"(x1));
 }
-template <int OFF, typename T>
+template <int OFF, bool DO = true, typename T>
 __device__ __forceinline__ void gap_read(Acc16 &c, const bf16x8 &a, const bf16x8 &b, T &rd, unsigned addr) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %4, %1\n\tds_read_b128 %2, %5 offset:%6"
                  : "+v"(c.lo), "+v"(c.hi), "=&v"(rd) : "v"(a), "v"(b), "v"(addr), "n"(OFF) : "memory");
@@ -1277,10 +1300,15 @@ conv_dma_kernel(const ConvParams p) {
         }
         lds_read16<0>(raw0, a_addr[0] + soff);
         lds_read16<0>(raw1, a_addr[1] + soff);
-        gap_read<0 * B_PLANE>(TSOD_MF(0), nxt.b[0][0], b_addr[0] + soff);
-        gap_read<0 * B_PLANE>(TSOD_MF(1), nxt.b[1][0], b_addr[1] + soff);
-        gap_read<0 * B_PLANE>(TSOD_MF(2), nxt.b[2][0], b_addr[2] + soff);
-        gap_read<0 * B_PLANE>(TSOD_MF(3), nxt.b[3][0], b_addr[3] + soff);
+#ifdef TSOD_DIAG_HALFMFMA
+#define TSOD_DO(n) (((n) >> 2) % 2 == 0)     /* timing probe only (make halfmfma): three of the six piece products, 12 MFMAs per phase */
+#else
+#define TSOD_DO(n) true
+#endif
+        gap_read<0 * B_PLANE, TSOD_DO(0)>(TSOD_MF(0), nxt.b[0][0], b_addr[0] + soff);
+        gap_read<0 * B_PLANE, TSOD_DO(1)>(TSOD_MF(1), nxt.b[1][0], b_addr[1] + soff);
+        gap_read<0 * B_PLANE, TSOD_DO(2)>(TSOD_MF(2), nxt.b[2][0], b_addr[2] + soff);
+        gap_read<0 * B_PLANE, TSOD_DO(3)>(TSOD_MF(3), nxt.b[3][0], b_addr[3] + soff);
         if constexpr (TABLE) {
             wait_lgkm_for<4>(t_e);                               // the entry, raw0, raw1 have landed (four younger reads may be out)
             const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)t_e.w);
@@ -1315,12 +1343,12 @@ conv_dma_kernel(const ConvParams p) {
         if constexpr (P > 5) TSOD_DMA(2 + 2 * G); else TSOD_DMA(1 + G);
 #else
 #define TSOD_SPLIT_GROUP(N0, X0, X1, G, PL, J0, J1)                                                        \
-        gap_cvt(TSOD_MF(N0), X0, X1, hh[G], t0, t1);                                                       \
-        gap_sub<PL * B_PLANE>(TSOD_MF(N0 + 1), r0, r1, X0, X1, t0, t1, nxt.b[J0][PL], b_addr[J0] + soff);  \
-        gap_cvt(TSOD_MF(N0 + 2), r0, r1, mm[G], t0, t1);                                                   \
+        gap_cvt<TSOD_DO(N0)>(TSOD_MF(N0), X0, X1, hh[G], t0, t1);                                          \
+        gap_sub<PL * B_PLANE, TSOD_DO(N0 + 1)>(TSOD_MF(N0 + 1), r0, r1, X0, X1, t0, t1, nxt.b[J0][PL], b_addr[J0] + soff);  \
+        gap_cvt<TSOD_DO(N0 + 2)>(TSOD_MF(N0 + 2), r0, r1, mm[G], t0, t1);                                  \
         if constexpr (P > 5) TSOD_DMA(1 + 2 * G);                                                          \
-        gap_sub<PL * B_PLANE>(TSOD_MF(N0 + 3), q0, q1, r0, r1, t0, t1, nxt.b[J1][PL], b_addr[J1] + soff);  \
-        gap_last(TSOD_MF(N0 + 4), q0, q1, ll[G]);                                                          \
+        gap_sub<PL * B_PLANE, TSOD_DO(N0 + 3)>(TSOD_MF(N0 + 3), q0, q1, r0, r1, t0, t1, nxt.b[J1][PL], b_addr[J1] + soff);  \
+        gap_last<TSOD_DO(N0 + 4)>(TSOD_MF(N0 + 4), q0, q1, ll[G]);                                         \
         if constexpr (P > 5) TSOD_DMA(2 + 2 * G); else TSOD_DMA(1 + G);
 #endif
         TSOD_SPLIT_GROUP(4, raw0.x, raw0.y, 0, 2, 0, 1)
