@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TSOD_VERSION 230 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
+#define TSOD_VERSION 231 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
                             ticket area in the workspace), pitched tsod_detections_f32, new entry points;
                             0.2.1: conv tiles fed by LDS-DMA (bf16x3), balanced K schedule (split_k = -2);
                             0.2.2: tsod_allgather_f32 + communicator helpers (RCCL bound at run time);
@@ -88,7 +88,14 @@ enum { TSOD_TILE_AUTO = 0, TSOD_TILE_128x128 = 1, TSOD_TILE_128x64 = 2, TSOD_TIL
  * v_mfma_f32_32x32x16_bf16: f32-level accuracy (error ~1.3e-7 of sum|a*b|) at 0.375x the matrix-pipe time; storage,
  * accumulation and epilogue are f32 either way.  Tiles available in BF16X3: 64x64, 64x64_S1, 128x64_W8_S1, 64x64_S1_K64,
  * 128x64_S1, 64x128_S1, 128x128_S1 (TSOD_ERR_UNSUPPORTED for the others). */
-enum { TSOD_PREC_F32 = 0, TSOD_PREC_BF16X3 = 1 };
+enum { TSOD_PREC_F32 = 0, TSOD_PREC_BF16X3 = 1, TSOD_PREC_FP16X2 = 2 };
+/* FP16X2 (experimental, TSOD_TILE_D128x128_K32 only): every f32 operand as TWO fp16 pieces of s * x
+ * (hi = rne(s x), lo = rne(s x - hi), s a power of two per tensor), THREE piece products per f32 product on
+ * v_mfma_f32_32x32x16_f16, f32 accumulation: the f32 kernel's accuracy with half the MFMAs of BF16X3 - while |s x| stays
+ * below fp16's 65504 (the CALLER picks desc.a_scale_exp for its activations' range; beyond it the products are inf).
+ * `w_packed` is then the image made by tsod_pack_conv_weight_fp16x2 with desc.w_scale_exp: [Cout][ceil(K/8)][hi | lo][8]
+ * fp16 of 2^w_scale_exp * w, 32 bytes per 8 k.  The accumulators are scaled back by 2^-(a_scale_exp + w_scale_exp) before
+ * the epilogue (exact), so scale / shift / residual / activation mean what they mean for the other arithmetics. */
 /* With TSOD_PREC_BF16X3 the `w_packed` argument of tsod_conv2d_f32 is the PRE-SPLIT weight image made once by
  * tsod_pack_conv_weight_bf16x3 from the f32 packed weights [Cout][K]: [Cout][ceil(K/8)][hi | mid | lo][8] bf16, 48 bytes per
  * 8 k (tsod_conv_weight_bf16x3_bytes), every weight cut exactly (hi + mid + lo == w).  Activations are split on the fly. */
@@ -126,6 +133,9 @@ typedef struct tsod_conv2d_desc {
      * stage of the TSOD_TILE_D* tiles): K-steps never straddle the sources nor run past c2.  A named tile that does not
      * divide them returns TSOD_ERR_UNSUPPORTED; TSOD_TILE_AUTO only considers tiles that do. */
     int32_t c2, in2_pitch, in2_off, stride2, H2, W2;
+    /* TSOD_PREC_FP16X2 only (ignored otherwise): the activations are split as 2^a_scale_exp * x, the weight image holds
+     * 2^w_scale_exp * w (the exponent it was packed with) */
+    int32_t a_scale_exp, w_scale_exp;
 } tsod_conv2d_desc;
 
 /* Packed weight layout Wp: [Cout][KH][KW][Cin] f32 (k = (kh*KW + kw)*Cin + ci, ci running over
@@ -138,6 +148,9 @@ int tsod_pack_conv_weight_f32(const float *w_oihw, int32_t Cout, int32_t Cin_src
 size_t tsod_conv_weight_bf16x3_bytes(int32_t Cout, int32_t K);
 int tsod_pack_conv_weight_bf16x3(const float *w_packed /* [Cout][K] f32 */, int32_t Cout, int32_t K, void *w_bf16x3,
                                  tsod_stream_t stream);
+size_t tsod_conv_weight_fp16x2_bytes(int32_t Cout, int32_t K);
+int tsod_pack_conv_weight_fp16x2(const float *w_packed /* [Cout][K] f32 */, int32_t Cout, int32_t K, int32_t w_scale_exp,
+                                 void *w_fp16x2, tsod_stream_t stream);
 
 /* Bytes of workspace tsod_conv2d_f32 needs for this descriptor (0 unless some tile is K-sliced).
  * Workspace contract: 16-byte aligned, private to one stream at a time, layout [one int32 arrival ticket per K-sliced

@@ -26,6 +26,7 @@ SHAPES = [(50, 84, 256, 256, 3, "layer3.conv2"), (25, 42, 512, 512, 3, "layer4.c
           (50, 84, 1024, 256, 1, "layer3.conv1"), (50, 84, 256, 1024, 1, "layer3.conv3"), (25, 42, 2048, 512, 1, "layer4.conv1"),
           (200, 334, 64, 64, 3, "layer1.conv2")]
 SCHEDS = [(17, 1), (18, 1), (18, 3), (20, 1), (22, 1), (22, 3), (22, -1)]
+PREC = int(os.environ.get("TSOD_TIMELINE_PREC", "1"))          # 1 = bf16x3, 2 = fp16x2 (tile d128x128k32 only)
 if len(sys.argv) > 2:
     SHAPES = [s for s in SHAPES if s[5] in sys.argv[2].split(",")]
 for (H, W, Cin, Cout, k, name) in SHAPES:
@@ -35,7 +36,13 @@ for (H, W, Cin, Cout, k, name) in SHAPES:
     fl = 2 * B * H * W * Cout * Cin * k * k
     print(f"--- {name}: B={B} {H}x{W} {Cin}->{Cout} k{k}  ({fl / 1e9:.2f} GFLOP)")
     for tile, split in SCHEDS:
-        fn = lambda: hip_ops.conv2d_nhwc(x, w, pad=k // 2, tile=tile, split_k=split, precision=1, residual=res, act=1, slope=0.25)  # noqa: E731
+        if PREC == 2:
+            wexp = hip_ops.fp16x2_weight_scale_exp(w)
+            w2 = hip_ops.pack_conv_weight_fp16x2(w, wexp)
+            fn = lambda: hip_ops.conv2d_nhwc(x, w, pad=k // 2, tile=tile, split_k=split, precision=2, residual=res, act=1, slope=0.25,  # noqa: E731
+                                             w2=w2, w_scale_exp=wexp)
+        else:
+            fn = lambda: hip_ops.conv2d_nhwc(x, w, pad=k // 2, tile=tile, split_k=split, precision=1, residual=res, act=1, slope=0.25)  # noqa: E731
         L.tsod_debug_set_dma_stamps(None)
         try:
             fn()

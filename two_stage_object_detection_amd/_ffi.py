@@ -21,8 +21,8 @@ TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "64x128", 5: 
               8: "64x64s1", 9: "128x64w8s1", 10: "64x64s1k64", 11: "128x64w8s1k64", 12: "64x64w1s1", 13: "128x64w2s1", 14: "128x64s1", 15: "64x128s1", 16: "128x128s1",
               17: "d128x128", 18: "d64x128", 19: "d256x128", 20: "d64x128s2", 21: "d128x256", 22: "d128x128k32"}
 TILE_IDS = tuple(range(1, 17))
-PREC_F32, PREC_BF16X3 = 0, 1
-PREC_NAMES = {0: "f32", 1: "bf16x3"}
+PREC_F32, PREC_BF16X3, PREC_FP16X2 = 0, 1, 2
+PREC_NAMES = {0: "f32", 1: "bf16x3", 2: "fp16x2"}
 DMA_TILE_IDS = (17, 18, 19, 20, 21, 22)                             # bf16x3 through LDS-DMA: one channel segment, Cin % 16 / % 32 == 0, bf16x3 ONLY
 BF16X3_TILE_IDS = (3, 8, 9, 10, 14, 15, 16) + DMA_TILE_IDS   # tiles that exist as bf16x3 variants (include/tsod.h)
 
@@ -42,6 +42,7 @@ class ConvDesc(Structure):
         ("OH", c_int32), ("OW", c_int32), ("act", c_int32), ("slope", c_float),
         ("res_pitch", c_int32), ("res_off", c_int32), ("tile", c_int32), ("split_k", c_int32), ("precision", c_int32),
         ("c2", c_int32), ("in2_pitch", c_int32), ("in2_off", c_int32), ("stride2", c_int32), ("H2", c_int32), ("W2", c_int32),
+        ("a_scale_exp", c_int32), ("w_scale_exp", c_int32),
     ]
 
 
@@ -53,6 +54,8 @@ _SIGNATURES = {
     "tsod_pack_conv_weight_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "tsod_conv_weight_bf16x3_bytes": (c_size_t, [c_int32, c_int32]),
     "tsod_pack_conv_weight_bf16x3": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "tsod_conv_weight_fp16x2_bytes": (c_size_t, [c_int32, c_int32]),
+    "tsod_pack_conv_weight_fp16x2": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "tsod_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "tsod_conv2d_resolve": (c_int, [POINTER(ConvDesc), POINTER(c_int32), POINTER(c_int32)]),
     "tsod_conv2d_f32": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -133,8 +136,8 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.tsod_version() != 230:
-            raise TsodError(f"{LIB_PATH} is version {l.tsod_version()}, this package binds version 230 of include/tsod.h: rebuild it "
+        if l.tsod_version() != 231:
+            raise TsodError(f"{LIB_PATH} is version {l.tsod_version()}, this package binds version 231 of include/tsod.h: rebuild it "
                             "(`make -C two_stage_object_detection_amd/csrc`)")
         _lib = l
     return _lib

@@ -62,6 +62,8 @@ struct ConvParams {
     // `split` K-slices, one workgroup per (tile, slice), partial sums reduced by conv_reduce_kernel
     int dp_tiles, split, ksteps_per_split;
     int sk_q;                     // > 0: balanced schedule (conv_dma_kernel): K-steps per workgroup of the tile-major K-step sequence
+    float a_scale, acc_scale;     // fp16x2 arithmetic only: activations are split as a_scale * x (a power of two), the accumulators
+                                  // are multiplied by acc_scale = 1 / (a_scale * weight scale) before the epilogue
     int ci_wrap;                  // channels a tap's run of K-steps covers before the next tap: Cin (tap-major), 32 (cmajor)
     int cmajor;                   // conv_dma_kernel, KH*KW > 1: K-steps run in (32-channel block, tap) order instead of (tap, channels):
                                   // a pixel's 128-byte line is used by all taps that touch it within KH*KW steps (L2-resident),
@@ -980,6 +982,49 @@ __device__ __forceinline__ void gap_read(f32x16 &c, const bf16x8 &a, const bf16x
     asm volatile("ds_read_b128 %1, %4 offset:%5" : "+v"(c), "=&v"(rd) : "v"(a), "v"(b), "v"(addr), "n"(OFF) : "memory");
 }
 
+// ---- "fp16x2" (TSOD_PREC_FP16X2): every operand as TWO fp16 pieces of s * x (hi = rne(s x), lo = rne(s x - hi), s a power of two
+// per tensor), THREE piece products per f32 product (lo*hi, hi*lo, hi*hi; the dropped lo*lo is 2^-22) on
+// v_mfma_f32_32x32x16_f16, f32 accumulation: the f32 kernel's accuracy with half the MFMAs of bf16x3 while |s x| < 65504.
+//   gap2_a:  MFMA; xs = s * x (two elements); h = rne_f16x2(xs); t = f32(h)
+//   gap2_b:  MFMA; r = xs - t (exact); l = rne_f16x2(r); one LDS fragment read of the next stage
+__device__ __forceinline__ void mfma_f16(f32x16 &c, const bf16x8 &a, const bf16x8 &b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <int OFF, typename T>
+__device__ __forceinline__ void gap2_read(f32x16 &c, const bf16x8 &a, const bf16x8 &b, T &rd, unsigned addr) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, %0\n\t"
+                 "ds_read_b128 %1, %4 offset:%5"
+                 : "+v"(c), "=&v"(rd) : "v"(a), "v"(b), "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void gap2_a(f32x16 &c, const bf16x8 &a, const bf16x8 &b, float x0, float x1, float sc, float &xs0, float &xs1,
+                                       unsigned &h, float &t0, float &t1) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %6, %7, %0\n\t"
+                 "v_mul_f32 %1, %10, %8\n\t"
+                 "v_mul_f32 %2, %10, %9\n\t"
+                 "v_cvt_pk_f16_f32 %3, %1, %2\n\t"
+                 "v_cvt_f32_f16 %4, %3\n\t"
+                 "v_cvt_f32_f16_sdwa %5, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
+                 : "+v"(c), "=&v"(xs0), "=&v"(xs1), "=&v"(h), "=&v"(t0), "=&v"(t1) : "v"(a), "v"(b), "v"(x0), "v"(x1), "s"(sc));
+}
+template <int OFF, typename T>
+__device__ __forceinline__ void gap2_b(f32x16 &c, const bf16x8 &a, const bf16x8 &b, float xs0, float xs1, float t0, float t1, float &r0, float &r1,
+                                       unsigned &l, T &rd, unsigned addr) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %5, %6, %0\n\t"
+                 "v_sub_f32 %1, %7, %9\n\t"
+                 "v_sub_f32 %2, %8, %10\n\t"
+                 "v_cvt_pk_f16_f32 %3, %1, %2\n\t"
+                 "ds_read_b128 %4, %11 offset:%12"
+                 : "+v"(c), "=&v"(r0), "=&v"(r1), "=&v"(l), "=&v"(rd) : "v"(a), "v"(b), "v"(xs0), "v"(xs1), "v"(t0), "v"(t1), "v"(addr), "n"(OFF) : "memory");
+}
+// the same split in plain code (the prologue's first stage): bit-identical to the statements above (rne both times)
+__device__ __forceinline__ void split2_pair(float x0, float x1, float sc, unsigned &h, unsigned &l) {
+    const float xs0 = sc * x0, xs1 = sc * x1;
+    const _Float16 h0 = (_Float16)xs0, h1 = (_Float16)xs1;
+    const _Float16 l0 = (_Float16)(xs0 - (float)h0), l1 = (_Float16)(xs1 - (float)h1);
+    h = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    l = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+}
+
 #ifdef TSOD_DIAG_MFMA16
 // timing probe only (make mfma16; wrong results by design): every v_mfma_f32_32x32x16_bf16 of the K loop replaced by TWO
 // v_mfma_f32_16x16x32_bf16 on the same operand registers (the same matrix-pipe cycles and FLOPs, the other shape's register
@@ -1014,14 +1059,15 @@ __device__ __forceinline__ void gap_read(Acc16 &c, const bf16x8 &a, const bf16x8
 }
 #endif
 
-constexpr int dma_stage_bytes(int bm, int bk, int bn = 128) { return bm * bk * 4 + 3 * bn * bk * 2; }
+constexpr int dma_stage_bytes(int bm, int bk, int bn = 128, int npl = 3) { return bm * bk * 4 + npl * bn * bk * 2; }
 constexpr int kDmaTabEntries = 640;   // K-steps of one workgroup's K range + ring depth + 1 (tile_ok_for keeps K / bk + 8 below it)
 constexpr unsigned kDmaSecondBit = 0x80000000u;   // validity-mask bit of the second source's 1x1 tap (filter taps use bits 0..30)
 
 // WAVES_N = 2: two columns of waves, BN = 256 - both read (and split) the same activation rows, each its own 128 output
 // channels: more FLOP per byte fetched from beyond the CU (the activation stage is shared) at the same 128-row granularity
-template <int BM, int BK, int WAVES_K, int S, bool BALANCED, int WAVES_N = 1>
-__global__ void __launch_bounds__((BM / 32) * WAVES_K * WAVES_N * 64, (2 * S * dma_stage_bytes(BM, BK, 128 * WAVES_N) <= 160 * 1024) ? 2 : 1)
+// NPL = pieces per operand: 3 = bf16x3 (six piece products per k chunk), 2 = fp16x2 (three)
+template <int BM, int BK, int WAVES_K, int S, bool BALANCED, int WAVES_N = 1, int NPL = 3>
+__global__ void __launch_bounds__((BM / 32) * WAVES_K * WAVES_N * 64, (2 * S * dma_stage_bytes(BM, BK, 128 * WAVES_N, NPL) <= 160 * 1024) ? 2 : 1)
 conv_dma_kernel(const ConvParams p) {
     constexpr int BN = 128 * WAVES_N, TN = 4, WAVES_M = BM / 32, WAVES = WAVES_M * WAVES_K * WAVES_N, THREADS = WAVES * 64;
     static_assert(BK == 16 * WAVES_K, "every wave owns one 16-k chunk of the stage");
@@ -1029,9 +1075,9 @@ conv_dma_kernel(const ConvParams p) {
     constexpr int A_ROW = BK * 4, B_ROW = BK * 2;                    // bytes per LDS row (A raw f32 / one bf16 plane of B)
     constexpr int A_SLOTS = A_ROW / 16, B_SLOTS = B_ROW / 16;        // 16-byte slots per row
     constexpr int A_RPL = 256 / A_ROW, B_RPL = 256 / B_ROW;          // rows per 256-byte bank line: slot ^= (row / RPL) & (SLOTS - 1)
-    constexpr int A_BYTES = BM * A_ROW, B_PLANE = BN * B_ROW, STAGE = dma_stage_bytes(BM, BK, BN);
+    constexpr int A_BYTES = BM * A_ROW, B_PLANE = BN * B_ROW, STAGE = dma_stage_bytes(BM, BK, BN, NPL);
     constexpr int A_RPP = 1024 / A_ROW, B_RPP = 1024 / B_ROW;        // rows per 1-KiB DMA piece
-    constexpr int A_PIECES = BM / A_RPP, B_PIECES = 3 * (BN / B_RPP);
+    constexpr int A_PIECES = BM / A_RPP, B_PIECES = NPL * (BN / B_RPP);
     static_assert(A_PIECES % WAVES == 0, "piece kinds per wave at compile time");
     // this wave's A pieces / all its pieces per stage; when the B pieces do not divide by the waves the last ones are
     // padding (an out-of-range source: zeros into a scratch KiB behind the stage), so that every wave counts the same vmcnt
@@ -1048,7 +1094,7 @@ conv_dma_kernel(const ConvParams p) {
     // ds_read_b128 per phase and a few vector operations on its result cost next to nothing (they issue in MFMA shadows).
     // Tiles whose ring fills the LDS of two workgroups per CU keep the scalar form (TABLE false).
     constexpr int TAB_N = kDmaTabEntries, TAB_BYTES = TAB_N * 16, TAB_OFF = S * STAGE + (B_PAD ? 1024 : 0);
-    constexpr int LB_WGS = (2 * S * dma_stage_bytes(BM, BK, 128 * WAVES_N) <= 160 * 1024) ? 2 : 1;
+    constexpr int LB_WGS = (2 * S * dma_stage_bytes(BM, BK, 128 * WAVES_N, NPL) <= 160 * 1024) ? 2 : 1;
     constexpr bool TABLE = LB_WGS * (TAB_OFF + TAB_BYTES) <= 160 * 1024;
     __shared__ __align__(16) unsigned char lds[TAB_OFF + (TABLE ? TAB_BYTES : 0)];
 
@@ -1142,7 +1188,7 @@ conv_dma_kernel(const ConvParams p) {
             const int row = rb * B_RPP + lane / B_SLOTS, phys = lane % B_SLOTS, logical = phys ^ ((row / B_RPL) & (B_SLOTS - 1));
             const int n = n0 + row;
             const bool real = qb < B_PIECES;
-            b_voff[i - PA_W] = (real && n < p.Cout) ? ((unsigned)n * (unsigned)kgroups + (unsigned)logical) * 48u + (unsigned)plane * 16u : kOOB;
+            b_voff[i - PA_W] = (real && n < p.Cout) ? ((unsigned)n * (unsigned)kgroups + (unsigned)logical) * (16u * NPL) + (unsigned)plane * 16u : kOOB;
             ldst[i] = real ? A_BYTES + plane * B_PLANE + rb * 1024 : S * STAGE;
         }
         ldst[i] = __builtin_amdgcn_readfirstlane(ldst[i] + lds0);
@@ -1186,7 +1232,7 @@ conv_dma_kernel(const ConvParams p) {
         u_second = u_kt >= k1_steps;                              // second source: a 1x1 tap, always inside the image
         const int d1 = ((u_kh * p.W + u_kw) * p.in_pitch + u_ci) * 4, d2 = (u_kt - k1_steps) * (BK * 4);
         // byte offset of k in a row of the weight image = (k / 8) * 48 = 6 k (k % 8 == 0); first source k = tap * Cin + channel
-        const int w1 = ((u_kh * p.KW + u_kw) * p.Cin + u_ci) * 6, w2 = u_kt * (BK * 6);
+        const int w1 = ((u_kh * p.KW + u_kw) * p.Cin + u_ci) * (2 * NPL), w2 = u_kt * (BK * 2 * NPL);
         u_delta = (unsigned)(u_second ? d2 : d1);
         u_woff = (unsigned)(u_second ? w2 : w1);
         u_rs_a[0] = u_second ? rs_in2[0] : rs_in[0];
@@ -1274,8 +1320,9 @@ conv_dma_kernel(const ConvParams p) {
         b_addr[j] = lds0 + A_BYTES + row * B_ROW + ((sl ^ sw) * 16);
     }
 
-    struct Frags { bf16x8 a[3], b[TN][3]; };
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // product q = A piece PA[q] x B piece PB[q] (smallest first)
+    struct Frags { bf16x8 a[NPL], b[TN][NPL]; };
+    // product q = A piece PA[q] x B piece PB[q] (smallest first); fp16x2: lo*hi, hi*lo, hi*hi
+    constexpr int PA[6] = {NPL == 3 ? 2 : 1, 0, NPL == 3 ? 1 : 0, 1, 0, 0}, PB[6] = {0, NPL == 3 ? 2 : 1, NPL == 3 ? 1 : 0, 0, 1, 0};
 
     // One phase.  MFMA n = 4 q + j (product q, accumulator j) runs on `cur`; the 14 LDS reads of the next stage go out in the
     // first gaps (A raw first), its A fragment is split behind MFMAs 4..23 (one pair per five MFMAs: h = rne(x); x -= h;
@@ -1288,6 +1335,57 @@ conv_dma_kernel(const ConvParams p) {
         unsigned hh[4], mm[4], ll[4];
         float t0, t1, r0, r1, q0, q1;
         const unsigned slot_off = (unsigned)(dma_slot * STAGE);
+      if constexpr (NPL == 2) {
+        // ---- fp16x2: 12 MFMAs (n = 4 q + j: product q of accumulator j).  The 10 LDS reads of the next stage go out in the first
+        // gaps (A raw first, then the hi plane of B) and behind every second MFMA of the rest (lo plane); the A fragment is
+        // split behind MFMAs 4..11, one pair of elements per two MFMAs; this wave's DMA pieces one per pair.
+#define TSOD_DMA2(I) do { if constexpr ((I) < P) issue_piece(std::integral_constant<int, (I)>{}, std::integral_constant<bool, TABLE>{}, slot_off); } while (0)
+#define TSOD_MF2(n) acc[0][(n) & 3], cur.a[PA[(n) >> 2]], cur.b[(n) & 3][PB[(n) >> 2]]
+        static_assert(NPL != 2 || P <= 5, "DMA slots of an fp16x2 phase");
+        float xs0, xs1;
+        if constexpr (TABLE) {
+            lds_read16<0>(t_e, tab_ptr);
+            tab_ptr += 16;
+        }
+        lds_read16<0>(raw0, a_addr[0] + soff);
+        lds_read16<0>(raw1, a_addr[1] + soff);
+        gap2_read<0>(TSOD_MF2(0), nxt.b[0][0], b_addr[0] + soff);
+        gap2_read<0>(TSOD_MF2(1), nxt.b[1][0], b_addr[1] + soff);
+        gap2_read<0>(TSOD_MF2(2), nxt.b[2][0], b_addr[2] + soff);
+        gap2_read<0>(TSOD_MF2(3), nxt.b[3][0], b_addr[3] + soff);
+        if constexpr (TABLE) {
+            wait_lgkm_for<4>(t_e);
+            const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)t_e.w);
+            t_woff = (unsigned)__builtin_amdgcn_readfirstlane((int)t_e.y);
+            t_second = (flags & 1u) != 0;
+            t_rs_w[0] = __builtin_amdgcn_readfirstlane(rs_w[0]);
+            t_rs_w[1] = __builtin_amdgcn_readfirstlane(rs_w[1]);
+            t_rs_w[2] = __builtin_amdgcn_readfirstlane((flags & 2u) ? 0 : rs_w[2]);
+            t_rs_w[3] = __builtin_amdgcn_readfirstlane(rs_w[3]);
+            t_rs_a[0] = __builtin_amdgcn_readfirstlane(t_second ? rs_in2[0] : rs_in[0]);
+            t_rs_a[1] = __builtin_amdgcn_readfirstlane(t_second ? rs_in2[1] : rs_in[1]);
+            t_rs_a[2] = __builtin_amdgcn_readfirstlane(t_second ? rs_in2[2] : rs_in[2]);
+            t_rs_a[3] = __builtin_amdgcn_readfirstlane(rs_in[3]);
+            TSOD_DMA2(0);
+        } else {
+            TSOD_DMA2(0);
+            wait_lgkm<4>();
+        }
+#define TSOD_SPLIT2(N0, X0, X1, G)                                                                        \
+        gap2_a(TSOD_MF2(N0), X0, X1, p.a_scale, xs0, xs1, hh[G], t0, t1);                                  \
+        gap2_b<B_PLANE>(TSOD_MF2(N0 + 1), xs0, xs1, t0, t1, r0, r1, ll[G], nxt.b[G][1], b_addr[G] + soff); \
+        TSOD_DMA2(1 + G);
+        TSOD_SPLIT2(4, raw0.x, raw0.y, 0)
+        TSOD_SPLIT2(6, raw0.z, raw0.w, 1)
+        TSOD_SPLIT2(8, raw1.x, raw1.y, 2)
+        TSOD_SPLIT2(10, raw1.z, raw1.w, 3)
+#undef TSOD_SPLIT2
+#undef TSOD_MF2
+#undef TSOD_DMA2
+        if constexpr (!TABLE) advance_stage();
+        nxt.a[0] = __builtin_bit_cast(bf16x8, (u32x4{hh[0], hh[1], hh[2], hh[3]}));
+        nxt.a[1] = __builtin_bit_cast(bf16x8, (u32x4{ll[0], ll[1], ll[2], ll[3]}));
+      } else {
 #define TSOD_DMA(I) do { if constexpr ((I) < P) issue_piece(std::integral_constant<int, (I)>{}, std::integral_constant<bool, TABLE>{}, slot_off); } while (0)
 #ifdef TSOD_DIAG_MFMA16
 #define TSOD_MF(n) pacc[(n) & 3], cur.a[PA[(n) >> 2]], cur.b[(n) & 3][PB[(n) >> 2]]
@@ -1361,7 +1459,8 @@ conv_dma_kernel(const ConvParams p) {
         if constexpr (!TABLE) advance_stage();
         nxt.a[0] = __builtin_bit_cast(bf16x8, (u32x4{hh[0], hh[1], hh[2], hh[3]}));
         nxt.a[1] = __builtin_bit_cast(bf16x8, (u32x4{mm[0], mm[1], mm[2], mm[3]}));
-        nxt.a[2] = __builtin_bit_cast(bf16x8, (u32x4{ll[0], ll[1], ll[2], ll[3]}));
+        nxt.a[NPL - 1] = __builtin_bit_cast(bf16x8, (u32x4{ll[0], ll[1], ll[2], ll[3]}));
+      }
     };
     // next stage visible to every wave; the ring slot of the stage that is now in registers may be refilled
     auto turn = [&]() {
@@ -1401,7 +1500,7 @@ conv_dma_kernel(const ConvParams p) {
                 u32x4 e = {0u, 0u, 0u, 2u};                       // dead: no row fetches, null weight descriptor
                 if (live) {
                     if (step >= k1_steps) {
-                        e = {(unsigned)((step - k1_steps) * (BK * 4)), (unsigned)(step * (BK * 6)), kDmaSecondBit, 1u};
+                        e = {(unsigned)((step - k1_steps) * (BK * 4)), (unsigned)(step * (BK * 2 * NPL)), kDmaSecondBit, 1u};
                     } else {
                         int tap, ci;
                         if (p.cmajor) {
@@ -1413,7 +1512,7 @@ conv_dma_kernel(const ConvParams p) {
                             ci = step * BK - tap * p.Cin;
                         }
                         const int kh = tap / p.KW, kw = tap - kh * p.KW;
-                        e = {(unsigned)(((kh * p.W + kw) * p.in_pitch + ci) * 4), (unsigned)((tap * p.Cin + ci) * 6), 1u << tap, 0u};
+                        e = {(unsigned)(((kh * p.W + kw) * p.in_pitch + ci) * 4), (unsigned)((tap * p.Cin + ci) * (2 * NPL)), 1u << tap, 0u};
                     }
                 }
                 *reinterpret_cast<u32x4 *>(lds + TAB_OFF + j * 16) = e;
@@ -1431,21 +1530,29 @@ conv_dma_kernel(const ConvParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) X.b[j][pl] = *reinterpret_cast<const bf16x8 *>(lds + (b_addr[j] - lds0) + pl * B_PLANE);
+                for (int pl = 0; pl < NPL; ++pl) X.b[j][pl] = *reinterpret_cast<const bf16x8 *>(lds + (b_addr[j] - lds0) + pl * B_PLANE);
             unsigned hh[4], mm[4], ll[4];
-            split3_pair(raw0.x, raw0.y, hh[0], mm[0], ll[0]);
-            split3_pair(raw0.z, raw0.w, hh[1], mm[1], ll[1]);
-            split3_pair(raw1.x, raw1.y, hh[2], mm[2], ll[2]);
-            split3_pair(raw1.z, raw1.w, hh[3], mm[3], ll[3]);
+            if constexpr (NPL == 2) {
+                split2_pair(raw0.x, raw0.y, p.a_scale, hh[0], ll[0]);
+                split2_pair(raw0.z, raw0.w, p.a_scale, hh[1], ll[1]);
+                split2_pair(raw1.x, raw1.y, p.a_scale, hh[2], ll[2]);
+                split2_pair(raw1.z, raw1.w, p.a_scale, hh[3], ll[3]);
+                mm[0] = mm[1] = mm[2] = mm[3] = 0;
+            } else {
+                split3_pair(raw0.x, raw0.y, hh[0], mm[0], ll[0]);
+                split3_pair(raw0.z, raw0.w, hh[1], mm[1], ll[1]);
+                split3_pair(raw1.x, raw1.y, hh[2], mm[2], ll[2]);
+                split3_pair(raw1.z, raw1.w, hh[3], mm[3], ll[3]);
+            }
             X.a[0] = __builtin_bit_cast(bf16x8, (u32x4{hh[0], hh[1], hh[2], hh[3]}));
             X.a[1] = __builtin_bit_cast(bf16x8, (u32x4{mm[0], mm[1], mm[2], mm[3]}));
-            X.a[2] = __builtin_bit_cast(bf16x8, (u32x4{ll[0], ll[1], ll[2], ll[3]}));
+            X.a[NPL - 1] = __builtin_bit_cast(bf16x8, (u32x4{ll[0], ll[1], ll[2], ll[3]}));
             // the compiler must finish its own LDS reads HERE: with one pending at the loop head it puts a conservative
             // lgkmcnt(0) in front of the first MFMA of every iteration
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(X.b[j][pl]));
+                for (int pl = 0; pl < NPL; ++pl) asm volatile("" : "+v"(X.b[j][pl]));
         }
         // phase i: MFMAs of stage i, LDS reads of stage i+1 (slot (i+1) % S), DMA of stage i+S into slot i % S
         int slot = 0;
@@ -1467,6 +1574,12 @@ conv_dma_kernel(const ConvParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // asm-issued MFMA results -> ordinary reads
     }
 #undef TSOD_DMA
+    if constexpr (NPL == 2) {                                    // back from (a_scale x) . (weight scale w) to x . w (a power of two: exact)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][j][e] *= p.acc_scale;
+    }
 #ifdef TSOD_DIAG_MFMA16
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -1574,6 +1687,27 @@ pack_weight_bf16x3_kernel(const float *__restrict__ w, int Cout, int K, unsigned
     }
 }
 
+// f32 packed weights [Cout][K] -> fp16x2 [Cout][ceil(K/8)][hi|lo][8] fp16 of scale * w (scale a power of two): hi = rne(s w),
+// lo = rne(s w - hi); k beyond K is zero.  One thread per 8-k group.
+__global__ void __launch_bounds__(256)
+pack_weight_fp16x2_kernel(const float *__restrict__ w, int Cout, int K, float scale, unsigned *__restrict__ out) {
+    const int groups = (K + 7) / 8;
+    const long total = (long)Cout * groups;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(t % groups);
+        const long n = t / groups;
+        unsigned *o = out + t * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = g * 8 + 2 * e;
+            unsigned h, l;
+            split2_pair(k < K ? w[n * K + k] : 0.f, k + 1 < K ? w[n * K + k + 1] : 0.f, scale, h, l);
+            o[e] = h;
+            o[4 + e] = l;
+        }
+    }
+}
+
 // resident = workgroups per CU (LDS / VGPR bound); dma = 1: conv_dma_kernel (bf16x3 only, nbuf = ring stages)
 struct TileInfo { int bm, bn, threads, resident; float cost; int bk, nbuf, bf16x3, dma; };
 const TileInfo kTiles[TSOD_TILE_COUNT] = {
@@ -1612,9 +1746,13 @@ int validate(const tsod_conv2d_desc *d) {
                  TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->act >= TSOD_ACT_NONE && d->act <= TSOD_ACT_RELU, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->tile >= 0 && d->tile < TSOD_TILE_COUNT && d->split_k >= -2 && d->split_k <= 64, TSOD_ERR_INVALID_ARG);
-    TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->precision == TSOD_PREC_BF16X3, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->precision == TSOD_PREC_BF16X3 || d->precision == TSOD_PREC_FP16X2, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->tile == TSOD_TILE_AUTO || kTiles[d->tile].bf16x3, TSOD_ERR_UNSUPPORTED);
-    TSOD_REQUIRE(d->precision == TSOD_PREC_BF16X3 || d->tile == TSOD_TILE_AUTO || !kTiles[d->tile].dma, TSOD_ERR_UNSUPPORTED);
+    TSOD_REQUIRE(d->precision != TSOD_PREC_F32 || d->tile == TSOD_TILE_AUTO || !kTiles[d->tile].dma, TSOD_ERR_UNSUPPORTED);
+    if (d->precision == TSOD_PREC_FP16X2) {                       // (experimental: the 128x128 / 32-k LDS-DMA tile only)
+        TSOD_REQUIRE(d->tile == TSOD_TILE_AUTO || d->tile == TSOD_TILE_D128x128_K32, TSOD_ERR_UNSUPPORTED);
+        TSOD_REQUIRE(d->a_scale_exp >= -24 && d->a_scale_exp <= 24 && d->w_scale_exp >= -40 && d->w_scale_exp <= 40, TSOD_ERR_INVALID_ARG);
+    }
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
     TSOD_REQUIRE(M < (int64_t)INT_MAX, TSOD_ERR_UNSUPPORTED);
     if (d->c2 != 0) {                                   // second source: a strided 1x1 tap of another tensor
@@ -1788,6 +1926,7 @@ Sched resolve(const tsod_conv2d_desc *d) {
         if (d->tile != TSOD_TILE_AUTO && d->tile != t) continue;
         if (d->precision && !kTiles[t].bf16x3) continue;
         if (!d->precision && kTiles[t].dma) continue;
+        if (d->precision == TSOD_PREC_FP16X2 && t != TSOD_TILE_D128x128_K32) continue;
         if (!tile_ok_for(d, t)) continue;        // (also an explicitly named tile: the caller gets TSOD_ERR_UNSUPPORTED)
         if (d->split_k != 0) {
             const Sched s = make_sched(d, t, d->split_k);
@@ -1806,12 +1945,12 @@ Sched resolve(const tsod_conv2d_desc *d) {
     return best;
 }
 
-template <int BM, int BK, int WAVES_K, int S, int WAVES_N = 1>
+template <int BM, int BK, int WAVES_K, int S, int WAVES_N = 1, int NPL = 3>
 void launch_dma_tile(const ConvParams &p, int grid, hipStream_t s) {
     if (p.sk_q > 0)
-        hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S, true, WAVES_N>), dim3(grid), dim3((BM / 32) * WAVES_K * WAVES_N * 64), 0, s, p);
+        hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S, true, WAVES_N, NPL>), dim3(grid), dim3((BM / 32) * WAVES_K * WAVES_N * 64), 0, s, p);
     else
-        hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S, false, WAVES_N>), dim3(grid), dim3((BM / 32) * WAVES_K * WAVES_N * 64), 0, s, p);
+        hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S, false, WAVES_N, NPL>), dim3(grid), dim3((BM / 32) * WAVES_K * WAVES_N * 64), 0, s, p);
 }
 
 template <int BM, int BN, int WM, int WN, int MW, int NBUF = 2, int BK = 32, int PREC = 0>
@@ -1881,7 +2020,8 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
         const uint64_t in_bytes = (uint64_t)d->N * d->H * d->W * d->in_pitch * sizeof(float);
         // bf16x3 weights are pre-split: [Cout][ceil(K/8)][hi|mid|lo][8] bf16 = 48 bytes per 8 k (tsod_pack_conv_weight_bf16x3)
         const uint64_t w_bytes = d->precision == TSOD_PREC_BF16X3 ? (uint64_t)d->Cout * ((p.K + 7) / 8) * 48
-                                                                  : (uint64_t)d->Cout * p.K * sizeof(float);
+                                 : d->precision == TSOD_PREC_FP16X2 ? (uint64_t)d->Cout * ((p.K + 7) / 8) * 32
+                                                                    : (uint64_t)d->Cout * p.K * sizeof(float);
         const uint64_t out_bytes = (uint64_t)p.M * d->out_pitch * sizeof(float);
         const uint64_t res_bytes = residual ? (uint64_t)p.M * d->res_pitch * sizeof(float) : 0;
         // 32-bit buffer offsets: one activation tensor must stay below 4 GiB (shard the batch otherwise)
@@ -1917,6 +2057,14 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
     p.part_bytes = (unsigned)(sc.ws_bytes - sc.ticket_bytes);
     TSOD_REQUIRE(sc.ws_bytes < 0xFFFFFFF0ull, TSOD_ERR_UNSUPPORTED);
     hipStream_t s = tsod_stream(stream);
+    p.a_scale = 1.f; p.acc_scale = 1.f;
+    if (d->precision == TSOD_PREC_FP16X2) {
+        TSOD_REQUIRE(sc.tile == TSOD_TILE_D128x128_K32, TSOD_ERR_UNSUPPORTED);
+        p.a_scale = ldexpf(1.f, d->a_scale_exp);
+        p.acc_scale = ldexpf(1.f, -(d->a_scale_exp + d->w_scale_exp));
+        launch_dma_tile<128, 32, 2, 3, 1, 2>(p, sc.grid, s);
+        return tsod_launch_status();
+    }
     if (d->precision == TSOD_PREC_BF16X3) {
         switch (sc.tile) {
             case TSOD_TILE_64x64_S1: launch_tile<64, 64, 32, 32, 5, 1, 32, 1>(p, sc.grid, s); break;
@@ -2000,6 +2148,23 @@ extern "C" int tsod_pack_conv_weight_bf16x3(const float *w_packed, int32_t Cout,
     const int blocks = (int)(tsod_cdiv(total, 256) < 4096 ? tsod_cdiv(total, 256) : 4096);
     hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), w_packed, Cout, K,
                        static_cast<unsigned *>(w_bf16x3));
+    return tsod_launch_status();
+}
+
+extern "C" size_t tsod_conv_weight_fp16x2_bytes(int32_t Cout, int32_t K) {
+    if (Cout <= 0 || K <= 0) return 0;
+    return (size_t)Cout * ((K + 7) / 8) * 32;
+}
+
+extern "C" int tsod_pack_conv_weight_fp16x2(const float *w_packed, int32_t Cout, int32_t K, int32_t w_scale_exp, void *w_fp16x2,
+                                            tsod_stream_t stream) {
+    TSOD_REQUIRE(w_packed && w_fp16x2, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(Cout > 0 && K > 0 && w_scale_exp >= -40 && w_scale_exp <= 40, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(tsod_aligned16(w_fp16x2), TSOD_ERR_ALIGNMENT);
+    const long total = (long)Cout * ((K + 7) / 8);
+    const int blocks = (int)(tsod_cdiv(total, 256) < 4096 ? tsod_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(pack_weight_fp16x2_kernel, dim3(blocks), dim3(256), 0, tsod_stream(stream), w_packed, Cout, K,
+                       ldexpf(1.f, w_scale_exp), static_cast<unsigned *>(w_fp16x2));
     return tsod_launch_status();
 }
 

@@ -130,6 +130,26 @@ def pack_conv_weight_bf16x3(w_packed: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def fp16x2_weight_scale_exp(w_packed: torch.Tensor) -> int:
+    """The power of two that brings max |w| just below 2^14 (fp16's largest finite value is 65504; the low pieces of weights
+    scaled like this stay out of its subnormals): the ``w_scale_exp`` of pack_conv_weight_fp16x2 and of the conv descriptor."""
+    import math
+    m = float(w_packed.abs().max())
+    return 0 if m == 0.0 or not math.isfinite(m) else max(-40, min(40, int(math.floor(math.log2(16384.0 / m)))))
+
+
+def pack_conv_weight_fp16x2(w_packed: torch.Tensor, w_scale_exp: int) -> torch.Tensor:
+    """f32 packed weights [Cout,KH,KW,Cin] -> the fp16x2 image tsod_conv2d_f32 reads with precision = fp16x2
+    (uint8 tensor of tsod_conv_weight_fp16x2_bytes: [Cout][ceil(K/8)][hi|lo][8] fp16 of 2^w_scale_exp * w)."""
+    require_cuda(w_packed, "pack_conv_weight_fp16x2")
+    w_packed = w_packed.contiguous()
+    cout = w_packed.shape[0]
+    K = w_packed.numel() // cout
+    out = torch.empty(lib().tsod_conv_weight_fp16x2_bytes(cout, K), dtype=torch.uint8, device=w_packed.device)
+    check(lib().tsod_pack_conv_weight_fp16x2(ptr(w_packed), cout, K, int(w_scale_exp), ptr(out), stream_ptr()), "pack_conv_weight_fp16x2")
+    return out
+
+
 _W3_CACHE: dict = {}
 
 
@@ -157,7 +177,7 @@ def _w3_for(w_packed: torch.Tensor) -> torch.Tensor:
 
 def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_logical=None, scale=None, shift=None,
                 residual=None, act=ACT_NONE, slope=0.0, segs=None, out=None, out_off=0, tile=0, split_k=0,
-                precision=0, x2=None, stride2=1, x2_off=0, w3=None) -> torch.Tensor:
+                precision=0, x2=None, stride2=1, x2_off=0, w3=None, a_scale_exp=4, w2=None, w_scale_exp=None) -> torch.Tensor:
     """Implicit-GEMM convolution on an NHWC tensor [N,H,W,P].  ``w_packed`` is [Cout,KH,KW,Cin]
     (see pack_conv_weight); ``kw_logical`` is the filter width before zero-tap padding (it fixes OW).
     ``segs`` = [(channel offset, length), ...] inside the P-wide pixel (default: the first Cin
@@ -166,7 +186,9 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
     last C2 columns contracting channels [x2_off, x2_off + C2) of pixel (oh*stride2, ow*stride2) of ``x2`` (``kernel`` =
     (KH, KW, Cin) of the first source must be given through ``segs`` / a 1x1 filter: only 1x1 first sources here).
     ``w3``: the pre-split bf16x3 image of ``w_packed`` (pack_conv_weight_bf16x3) when the caller keeps one; used with
-    ``precision`` = bf16x3 instead of the wrapper's own cache."""
+    ``precision`` = bf16x3 instead of the wrapper's own cache.  ``precision`` = fp16x2 (experimental): activations are split as
+    2^``a_scale_exp`` * x (|that| must stay below 65504), ``w2`` / ``w_scale_exp`` = the fp16x2 weight image and the exponent it
+    was packed with (made on the spot from ``w_packed`` when not given)."""
     require_cuda(x, "conv2d")
     assert x.is_contiguous() and w_packed.is_contiguous()
     N, H, W, P = x.shape
@@ -188,10 +210,15 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
                        KH=KH, KW=KW, stride=stride, pad_h=pad, pad_w=pad, OH=OH, OW=OW, act=act, slope=slope,
                        res_pitch=0 if residual is None else residual.shape[-1], res_off=0, tile=tile, split_k=split_k,
                        precision=precision, src2=src2)
+    if precision == _ffi.PREC_FP16X2:
+        if w2 is None:
+            w_scale_exp = fp16x2_weight_scale_exp(w_packed)
+            w2 = pack_conv_weight_fp16x2(w_packed, w_scale_exp)
+        d.a_scale_exp, d.w_scale_exp = int(a_scale_exp), int(w_scale_exp)
     ws_bytes = lib().tsod_conv2d_workspace_bytes(byref(d))
     ws = CONV_ARENA.get(x.device, ws_bytes) if ws_bytes else None
-    # bf16x3 reads the pre-split weight image
-    w_arg = (w3 if w3 is not None else _w3_for(w_packed)) if precision == _ffi.PREC_BF16X3 else w_packed
+    # bf16x3 / fp16x2 read their pre-split weight images
+    w_arg = (w3 if w3 is not None else _w3_for(w_packed)) if precision == _ffi.PREC_BF16X3 else (w2 if precision == _ffi.PREC_FP16X2 else w_packed)
     check(lib().tsod_conv2d_dual_f32(byref(d), ptr(x), ptr(x2), ptr(w_arg), ptr(scale), ptr(shift), ptr(residual), ptr(out),
                                      ptr(ws), ws_bytes, stream_ptr()), "conv2d")
     return out
