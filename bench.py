@@ -66,6 +66,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfm
 BF16_MFMA_PEAK_TFLOPS = 2516.8   # same guide: ~2.5 PF dense bf16 MFMA = 16x the f32 MFMA rate
 # bf16x3 executes SIX bf16 MFMA products per f32 product: its roofline in f32-equivalent (algorithmic) FLOPs
 BF16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+FP16X2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0       # fp16 dense MFMA = the bf16 rate; three piece products per f32 product
 R_POST = 300
 
 
@@ -82,9 +83,11 @@ def parse(argv=None):
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--num-classes", type=int, default=80)
     ap.add_argument("--no-autotune", action="store_true")
-    ap.add_argument("--precision", default="auto", choices=("f32", "bf16x3", "auto"), help="arithmetic of the conv GEMMs: f32 = "
+    ap.add_argument("--precision", default="auto", choices=("f32", "bf16x3", "auto", "fp16x2"), help="arithmetic of the conv GEMMs: f32 = "
                     "v_mfma_f32_32x32x2_f32; bf16x3 = three exact bf16 pieces per operand on v_mfma_f32_32x32x16_bf16 "
-                    "(f32-accurate, gated by the same parity suite); auto = the autotuner picks per layer")
+                    "(f32-accurate, gated by the same parity suite); auto = the autotuner picks per layer; fp16x2 = auto with the "
+                    "EXPERIMENTAL third arithmetic among the candidates (two fp16 pieces of 16 x per operand, three products: "
+                    "f32-accurate while |x| < 4094 - opt-in, not the default line)")
     ap.add_argument("--autotune-concurrent", type=int, default=None, help="copies of a candidate in flight on separate streams while "
                     "the in-flight tile table is tuned (default: --in-flight, i.e. 4: measured 697 -> 754 images/s on one box "
                     "against tuning with 2 copies; 6 and 8 are no better)")
@@ -484,7 +487,7 @@ def main(argv=None):
                                            # there and only lengthens the tuning pass (8 ranks tune at once in the N > 1 runs)
         tiles_loaded = bool(args.tiles_file and os.path.exists(args.tiles_file))
         t_tune = time.perf_counter()
-        precs = {"f32": (0,), "bf16x3": (1,), "auto": (0, 1)}[args.precision]
+        precs = {"f32": (0,), "bf16x3": (1,), "auto": (0, 1), "fp16x2": (0, 1, 2)}[args.precision]
         if tiles_loaded:
             tiles = json.load(open(args.tiles_file))
         elif not args.no_autotune and world > 1:
@@ -573,9 +576,9 @@ def main(argv=None):
         conv_flops = sum(st.flops for st in plan.conv_steps)
         algo_bytes = conv_algorithmic_bytes(plan)
         precs = [int(st.desc.precision) for st in plan.conv_steps]
-        flops_bf = sum(st.flops for st, pr in zip(plan.conv_steps, precs) if pr == 1)
-        ideal_ms = sum(st.flops / ((BF16X3_PEAK_TFLOPS if pr == 1 else F32_MFMA_PEAK_TFLOPS) * 1e12) * 1e3
-                       for st, pr in zip(plan.conv_steps, precs))
+        flops_bf = sum(st.flops * (6 if pr == 1 else 3) for st, pr in zip(plan.conv_steps, precs) if pr >= 1) / 6.0
+        peak_of = {0: F32_MFMA_PEAK_TFLOPS, 1: BF16X3_PEAK_TFLOPS, 2: FP16X2_PEAK_TFLOPS}
+        ideal_ms = sum(st.flops / (peak_of[pr] * 1e12) * 1e3 for st, pr in zip(plan.conv_steps, precs))
         if args.no_graph:
             n_fly = 1
 
@@ -628,7 +631,8 @@ def main(argv=None):
         conv_total_ms = conv_seq_ms                                       # one pass in forward order (agrees with the kernel trace)
         achieved = conv_flops / (conv_total_ms * 1e-3) / 1e12
         eff_peak = conv_flops / (ideal_ms * 1e-3) / 1e12               # FLOP-weighted harmonic peak of the layers' arithmetics
-        n_bf = sum(precs)
+        n_bf = sum(1 for pr in precs if pr == 1)
+        n_h2 = sum(1 for pr in precs if pr == 2)
         traffic, traffic_note = (None, "skipped") if (n_gpus > 1 or args.no_pmc) else pmc_traffic(args, tiles["serial"], len(conv_ms))
         step_flops = conv_flops                                           # conv GEMM FLOPs of one step (B images)
         line = {
@@ -637,8 +641,11 @@ def main(argv=None):
             "value": round(n_gpus * B / (head["ms_per_step"] * 1e-3), 3), "unit": "images/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(head["ms_per_step"], 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if n_bf == 0 else "f32 storage/accumulate; conv products as bf16x3 (3 exact bf16 pieces per operand, "
-                                              f"6 bf16 MFMAs per product) in {n_bf} of {len(precs)} conv layers, f32 MFMA in the rest",
+            "dtype": "f32" if n_bf + n_h2 == 0 else "f32 storage/accumulate; conv products as bf16x3 (3 exact bf16 pieces per operand, "
+                                              f"6 bf16 MFMAs per product) in {n_bf} of {len(precs)} conv layers, "
+                                              + (f"as fp16x2 (EXPERIMENTAL, opt-in: 2 fp16 pieces of 16 x per operand, 3 fp16 MFMAs per "
+                                                 f"product, f32-accurate while |x| < 4094) in {n_h2}, " if n_h2 else "")
+                                              + "f32 MFMA in the rest",
             "data": "synthetic",
             "config": {"workload": f"Full Faster R-CNN {args.backbone} inference forward, batch={B} per GPU, "
                                    f"3x{args.height}x{args.width}, {args.num_classes}+1 classes, 3000->300 proposals"
@@ -661,7 +668,9 @@ def main(argv=None):
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(eff_peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / eff_peak, 4),
                          "peak_note": f"f32-equivalent: {n_bf} layers bf16x3 (bf16 dense MFMA {BF16_MFMA_PEAK_TFLOPS} / 6 products = "
-                                      f"{BF16X3_PEAK_TFLOPS:.1f}), {len(precs) - n_bf} layers f32 MFMA ({F32_MFMA_PEAK_TFLOPS}); FLOP-weighted "
+                                      f"{BF16X3_PEAK_TFLOPS:.1f}), "
+                                      + (f"{n_h2} layers fp16x2 (/ 3 products = {FP16X2_PEAK_TFLOPS:.1f}), " if n_h2 else "")
+                                      + f"{len(precs) - n_bf - n_h2} layers f32 MFMA ({F32_MFMA_PEAK_TFLOPS}); FLOP-weighted "
                                       "harmonic mean, i.e. frac = sum of ideal matrix-pipe times / measured time",
                          "executed_bf16_mfma_tflops": round(6.0 * flops_bf / (conv_total_ms * 1e-3) / 1e12, 1),
                          "traffic": None if traffic is None else round(traffic),

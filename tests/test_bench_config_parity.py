@@ -146,6 +146,51 @@ def test_detector_after_the_in_sequence_autotune(dev, r50):
         plan.import_tiles(before)
 
 
+def test_detector_with_the_fp16x2_arithmetic_among_the_candidates(dev, r50):
+    """`bench.py --precision fp16x2` (EXPERIMENTAL, opt-in): the third arithmetic - two fp16 pieces of 16 x per operand, three
+    piece products per f32 product on v_mfma_f32_32x32x16_f16 - competes per layer; then the same with every layer that can
+    take it FORCED onto it (so the gate does not depend on what the clock picked).  Same bars as every other tile table: the
+    oracle's RoIs, no unmatched row, no class mismatch.  (The synthetic trunk's activations reach abs-max ~100: inside the
+    arithmetic's range of 4094.)"""
+    import ctypes
+    from two_stage_object_detection_amd import _ffi
+    from two_stage_object_detection_amd.testing import compare_detector_outputs
+    model, sd, x, ref = r50
+    xg = x.to(dev)
+    with torch.inference_mode():
+        model(xg)
+        plan = model.extractor._plan_for(xg)
+        before = plan.export_tiles()
+        plan.autotune(reps=2, concurrent=1, precisions=(0, 1, 2))
+        tuned = plan.export_tiles()
+        n_h2 = sum(1 for r in tuned if r[3] == _ffi.PREC_FP16X2)
+        got = [o.cpu() for o in model(xg)]
+        model.raise_if_error()
+        rep = compare_detector_outputs(got, ref)
+        print("fp16x2 among the candidates: picked for", n_h2, "of", len(tuned), "layers", rep)
+        assert n_h2 >= 8, tuned                                           # it wins wherever the LDS-DMA tile does
+        assert rep["ok"] and rep["rows_positional_mismatch"] <= 4 and rep["rows_unmatched"] == 0 and rep["class_mismatch"] == 0, rep
+        forced = []
+        for st, (name, tile, split, prec) in zip(plan.conv_steps, tuned):
+            try:
+                st.choose(22, split if tile == 22 else -1, _ffi.PREC_FP16X2)
+                t_, s_ = ctypes.c_int32(0), ctypes.c_int32(0)
+                if _ffi.lib().tsod_conv2d_resolve(ctypes.byref(st.desc), ctypes.byref(t_), ctypes.byref(s_)) != 0:
+                    raise _ffi.TsodError("unsupported")
+                forced.append((name, 22, split if tile == 22 else -1, _ffi.PREC_FP16X2))
+            except _ffi.TsodError:
+                forced.append((name, tile, split, prec))
+        plan.import_tiles(forced)
+        n_forced = sum(1 for r in forced if r[3] == _ffi.PREC_FP16X2)
+        got = [o.cpu() for o in model(xg)]
+        model.raise_if_error()
+        rep = compare_detector_outputs(got, ref)
+        print("fp16x2 forced on", n_forced, "layers", rep)
+        assert n_forced >= 30, forced
+        assert rep["ok"] and rep["rows_positional_mismatch"] <= 4 and rep["rows_unmatched"] == 0 and rep["class_mismatch"] == 0, rep
+        plan.import_tiles(before)
+
+
 def test_detector_after_the_in_flight_refinement(dev, r50):
     """bench.py's IN-FLIGHT table (round 3): after the first look (copies of one layer side by side) the three fastest
     candidates of every layer are tried again while all slots' streams run the whole conv sequence staggered around it

@@ -575,6 +575,74 @@ def test_conv_dual_source_is_the_sum_of_two_convs(ops, dev, C1, C2, Cout, stride
         _ffi.check(_ffi.lib().tsod_conv2d_f32(byref(d), _ffi.ptr(yn), _ffi.ptr(w), None, None, None, _ffi.ptr(out), None, 0, None))
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,res", [(1, 256, 256, 50, 84, 3, False), (2, 1024, 256, 25, 21, 1, False), (1, 512, 2048, 13, 21, 1, True),
+                                                  (1, 64, 64, 37, 41, 3, True), (1, 128, 96, 19, 23, 3, False)])
+def test_conv_fp16x2_matches_the_f64_convolution(ops, dev, N, Cin, Cout, H, W, k, res):
+    """TSOD_PREC_FP16X2 (experimental; tile d128x128k32): two fp16 pieces of 16 x per operand, three piece products per f32
+    product.  Held to the bf16x3 / f32 bar against the f64 CPU convolution under every K schedule, and to <= 2x the error of the
+    bf16x3 form of the same launch (measured: below it)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    x = torch.maximum(x, 0.25 * x)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(k * k * Cin)
+    r = torch.randn(N, Cout, H, W, generator=g) if res else None
+    ref = F.conv2d(x.double(), w.double(), padding=k // 2)
+    if res:
+        ref = ref + r.double()
+    ref = torch.where(ref >= 0, ref, 0.25 * ref).float()
+    xn, wp = ops.nchw_to_nhwc(x.to(dev)), ops.pack_conv_weight(w.to(dev))
+    rn = ops.nchw_to_nhwc(r.to(dev)) if res else None
+    tol = 3e-6 * math.sqrt(k * k * Cin) + 1e-5
+    e3 = (ops.nhwc_to_nchw(ops.conv2d_nhwc(xn, wp, pad=k // 2, tile=22, split_k=1, precision=1, residual=rn, act=1, slope=0.25)).cpu() - ref).abs().max().item()
+    for split in (1, 3, -1, -2):
+        out = ops.conv2d_nhwc(xn, wp, pad=k // 2, tile=22, split_k=split, precision=2, residual=rn, act=1, slope=0.25, a_scale_exp=4)
+        e = (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item()
+        assert e <= tol and e <= 2 * e3 + 1e-7, (split, e, e3, tol)
+
+
+def test_conv_fp16x2_second_source_range_and_gates(ops, dev):
+    """The rest of the fp16x2 contract: the stacked-K form with a second source (a bottleneck's conv3 + projection shortcut)
+    matches the two f64 convolutions added up; only tile d128x128k32 takes the arithmetic (others: TSOD_ERR_UNSUPPORTED,
+    TSOD_TILE_AUTO resolves to it); what happens beyond the range (|x| >= 65504 / 2^a_scale_exp) is pinned down as it IS: the
+    pieces overflow to +-inf, their products cancel to NaN, and the branch-free activation of the epilogue maps NaN to 0 - the
+    outputs the value feeds come out 0, everything else is untouched, nothing is reported (the caller owns the range: this is
+    why the arithmetic is opt-in until the scale follows the tensor); a smaller exponent brings the value
+    back into range."""
+    from two_stage_object_detection_amd._ffi import TsodError
+    g = torch.Generator().manual_seed(36)
+    C1, C2, Cout, H2, W2 = 64, 96, 128, 11, 13
+    y = torch.randn(2, C1, H2, W2, generator=g)
+    x = torch.randn(2, C2, H2, W2, generator=g)
+    w3 = torch.randn(Cout, C1, 1, 1, generator=g) / math.sqrt(C1)
+    wd = torch.randn(Cout, C2, 1, 1, generator=g) / math.sqrt(C2)
+    ref = (F.conv2d(y.double(), w3.double()) + F.conv2d(x.double(), wd.double())).float()
+    yn, xn = ops.nchw_to_nhwc(y.to(dev)), ops.nchw_to_nhwc(x.to(dev))
+    w = torch.cat([w3.flatten(1), wd.flatten(1)], dim=1).contiguous().to(dev)
+    tol = 3e-6 * math.sqrt(C1 + C2) + 1e-5
+    for split in (1, -1, 2):
+        out = ops.conv2d_nhwc(yn, w, segs=[(0, C1)], tile=22, split_k=split, precision=2, x2=xn)
+        assert (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item() <= tol, split
+    out = ops.conv2d_nhwc(yn, w, segs=[(0, C1)], precision=2, x2=xn)                  # AUTO
+    assert (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item() <= tol
+    for tile in (3, 14, 17, 18, 21):
+        with pytest.raises(TsodError, match="unsupported|UNSUPPORTED"):
+            ops.conv2d_nhwc(yn, w, segs=[(0, C1)], tile=tile, split_k=1, precision=2, x2=xn)
+    # range: one activation of 5000 with a_scale_exp = 4 (16 * 5000 > 65504)
+    xb = torch.randn(1, 64, 9, 9, generator=g)
+    xb[0, 3, 4, 4] = 5000.0
+    wb = torch.randn(32, 64, 3, 3, generator=g) / 24.0
+    refb = F.conv2d(xb.double(), wb.double(), padding=1).float()
+    xbn, wbp = ops.nchw_to_nhwc(xb.to(dev)), ops.pack_conv_weight(wb.to(dev))
+    bad = ops.nhwc_to_nchw(ops.conv2d_nhwc(xbn, wbp, pad=1, tile=22, split_k=1, precision=2, a_scale_exp=4)).cpu()
+    touched = torch.zeros(1, 1, 9, 9, dtype=torch.bool)
+    touched[0, 0, 3:6, 3:6] = True
+    hit = bad[touched.expand_as(bad)]
+    assert ((hit == 0) | ~torch.isfinite(hit)).all()                                  # every output the value feeds: 0 (from NaN) or inf
+    assert (bad[~touched.expand_as(bad)] - refb[~touched.expand_as(bad)]).abs().max().item() <= 1e-4
+    good = ops.nhwc_to_nchw(ops.conv2d_nhwc(xbn, wbp, pad=1, tile=22, split_k=1, precision=2, a_scale_exp=2)).cpu()
+    assert (good - refb).abs().max().item() <= 2e-3 * 1.0                            # (values ~100: 5000 * w; f32-level relative error)
+
+
 def test_conv_dma_tiles_stage_table_limits_and_step_order(ops, dev):
     """The LDS-DMA tiles keep one table entry per K-step of a workgroup's K range (640 entries): a K that needs more steps than
     that at a tile's stage size is REFUSED for that tile when named and never picked by TSOD_TILE_AUTO, while the tiles with

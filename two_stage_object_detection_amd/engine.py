@@ -96,6 +96,22 @@ def weights_bf16x3(pc) -> torch.Tensor:
     return w3
 
 
+FP16X2_A_SCALE_EXP = 4     # activations are split as 2^4 * x under the fp16x2 arithmetic: |x| < 4094 (65504 / 16) is its range
+
+
+def weights_fp16x2(pc):
+    """(fp16x2 image, w_scale_exp) of a packed layer's weights (experimental arithmetic, include/tsod.h TSOD_PREC_FP16X2),
+    made on first use and kept beside the f32 weights; the exponent brings max |w| just below 2^14."""
+    hit = getattr(pc, "w2", None)
+    if hit is None:
+        from . import hip_ops
+        e = hip_ops.fp16x2_weight_scale_exp(pc.w)
+        hit = pc.w2 = (hip_ops.pack_conv_weight_fp16x2(pc.w, e), e)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(pc.w.device).synchronize()
+    return hit
+
+
 def prelu_slope(m: torch.nn.PReLU) -> float:
     if m.weight.numel() != 1:
         raise TsodError("only single-parameter nn.PReLU is supported (what the reference uses)")
@@ -145,7 +161,12 @@ class ConvStep:
         """Pin (tile, K-slice schedule, arithmetic); the weight argument follows the arithmetic (f32 or pre-split bf16x3)."""
         d = self.desc
         d.tile, d.split_k, d.precision = int(tile), int(split_k), int(precision)
-        self.args[self.w_index] = ptr(weights_bf16x3(self.pc)) if precision == _ffi.PREC_BF16X3 else ptr(self.pc.w)
+        if precision == _ffi.PREC_FP16X2:
+            w2, e = weights_fp16x2(self.pc)
+            d.a_scale_exp, d.w_scale_exp = FP16X2_A_SCALE_EXP, int(e)
+            self.args[self.w_index] = ptr(w2)
+        else:
+            self.args[self.w_index] = ptr(weights_bf16x3(self.pc)) if precision == _ffi.PREC_BF16X3 else ptr(self.pc.w)
 
 
 class Plan:
@@ -297,7 +318,8 @@ class Plan:
             M = d.N * d.OH * d.OW
             cands = []
             for prec in (precisions if precisions is not None else (int(d.precision),)):
-                for tile in (_ffi.BF16X3_TILE_IDS if prec == _ffi.PREC_BF16X3 else _ffi.TILE_IDS):
+                for tile in (_ffi.BF16X3_TILE_IDS if prec == _ffi.PREC_BF16X3 else (_ffi.FP16X2_TILE_IDS if prec == _ffi.PREC_FP16X2
+                                                                                    else _ffi.TILE_IDS)):
                     for split in (splits or (1, -1, -2, 2, 3, 4, 6, 8, 12, 16, 24, 32)):
                         if split > 1 and ksteps // split < 2:
                             continue
@@ -366,7 +388,7 @@ class Plan:
             def beyond_l2(tile, split, prec):
                 st.choose(tile, split, prec)
                 slabs = max(0, int(lib().tsod_conv2d_workspace_bytes(byref(d))) - (256 << 10))
-                wbytes = d.Cout * K * (6 if prec == _ffi.PREC_BF16X3 else 4)
+                wbytes = d.Cout * K * (6 if prec == _ffi.PREC_BF16X3 else 4)   # (fp16x2: 4)
                 m = re.search(r"(\d+)x(\d+)", TILE_NAMES[tile])
                 tiles_m = -(-M // int(m.group(1))) if m else 8
                 return 2 * slabs + wbytes * (tiles_m if split == -2 else 8)
