@@ -92,7 +92,8 @@ enum { TSOD_PREC_F32 = 0, TSOD_PREC_BF16X3 = 1, TSOD_PREC_FP16X2 = 2 };
 /* FP16X2 (experimental, TSOD_TILE_D128x128_K32 only): every f32 operand as TWO fp16 pieces of s * x
  * (hi = rne(s x), lo = rne(s x - hi), s a power of two per tensor), THREE piece products per f32 product on
  * v_mfma_f32_32x32x16_f16, f32 accumulation: the f32 kernel's accuracy with half the MFMAs of BF16X3 - while |s x| stays
- * below fp16's 65504 (the CALLER picks desc.a_scale_exp for its activations' range; beyond it the products are inf).
+ * below fp16's 65504 (the CALLER picks desc.a_scale_exp for its activations' range; beyond it the piece products are inf /
+ * NaN, reported through desc.range_flag).
  * `w_packed` is then the image made by tsod_pack_conv_weight_fp16x2 with desc.w_scale_exp: [Cout][ceil(K/8)][hi | lo][8]
  * fp16 of 2^w_scale_exp * w, 32 bytes per 8 k.  The accumulators are scaled back by 2^-(a_scale_exp + w_scale_exp) before
  * the epilogue (exact), so scale / shift / residual / activation mean what they mean for the other arithmetics. */
@@ -136,6 +137,11 @@ typedef struct tsod_conv2d_desc {
     /* TSOD_PREC_FP16X2 only (ignored otherwise): the activations are split as 2^a_scale_exp * x, the weight image holds
      * 2^w_scale_exp * w (the exponent it was packed with) */
     int32_t a_scale_exp, w_scale_exp;
+    /* TSOD_PREC_FP16X2 only, optional (NULL: no report): a device int32 that the launch ORs 1 into when a workgroup ends its K
+     * loop with a non-finite accumulator - which is what an activation outside the range produces in every output it feeds
+     * (and what genuinely non-finite input produces).  The outputs of such a launch are not to be used; clear the word and
+     * run the layer with TSOD_PREC_BF16X3 or a smaller a_scale_exp. */
+    int32_t *range_flag;
 } tsod_conv2d_desc;
 
 /* Packed weight layout Wp: [Cout][KH][KW][Cin] f32 (k = (kh*KW + kw)*Cin + ci, ci running over

@@ -188,6 +188,12 @@ def test_detector_with_the_fp16x2_arithmetic_among_the_candidates(dev, r50):
         print("fp16x2 forced on", n_forced, "layers", rep)
         assert n_forced >= 30, forced
         assert rep["ok"] and rep["rows_positional_mismatch"] <= 4 and rep["rows_unmatched"] == 0 and rep["class_mismatch"] == 0, rep
+        # the range guard end to end: an image scaled out of the arithmetic's range must raise, not return boxes
+        model(xg * 1e4)
+        with pytest.raises(_ffi.TsodError, match="fp16x2"):
+            model.raise_if_error()
+        model(xg)
+        model.raise_if_error()                                             # ... and the flag was cleared by the raise
         plan.import_tiles(before)
 
 

@@ -605,9 +605,9 @@ def test_conv_fp16x2_second_source_range_and_gates(ops, dev):
     matches the two f64 convolutions added up; only tile d128x128k32 takes the arithmetic (others: TSOD_ERR_UNSUPPORTED,
     TSOD_TILE_AUTO resolves to it); what happens beyond the range (|x| >= 65504 / 2^a_scale_exp) is pinned down as it IS: the
     pieces overflow to +-inf, their products cancel to NaN, and the branch-free activation of the epilogue maps NaN to 0 - the
-    outputs the value feeds come out 0, everything else is untouched, nothing is reported (the caller owns the range: this is
-    why the arithmetic is opt-in until the scale follows the tensor); a smaller exponent brings the value
-    back into range."""
+    outputs the value feeds come out 0, everything else is untouched - and the launch raises desc.range_flag (every workgroup
+    checks its accumulators behind the K loop: a finite tile proves its inputs were in range), under every K schedule; a
+    smaller exponent brings the value back into range and leaves the flag alone."""
     from two_stage_object_detection_amd._ffi import TsodError
     g = torch.Generator().manual_seed(36)
     C1, C2, Cout, H2, W2 = 64, 96, 128, 11, 13
@@ -633,13 +633,21 @@ def test_conv_fp16x2_second_source_range_and_gates(ops, dev):
     wb = torch.randn(32, 64, 3, 3, generator=g) / 24.0
     refb = F.conv2d(xb.double(), wb.double(), padding=1).float()
     xbn, wbp = ops.nchw_to_nhwc(xb.to(dev)), ops.pack_conv_weight(wb.to(dev))
-    bad = ops.nhwc_to_nchw(ops.conv2d_nhwc(xbn, wbp, pad=1, tile=22, split_k=1, precision=2, a_scale_exp=4)).cpu()
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    bad = ops.nhwc_to_nchw(ops.conv2d_nhwc(xbn, wbp, pad=1, tile=22, split_k=1, precision=2, a_scale_exp=4, range_flag=flag)).cpu()
+    assert int(flag.item()) == 1                                                       # ... and the launch SAYS so
     touched = torch.zeros(1, 1, 9, 9, dtype=torch.bool)
     touched[0, 0, 3:6, 3:6] = True
     hit = bad[touched.expand_as(bad)]
     assert ((hit == 0) | ~torch.isfinite(hit)).all()                                  # every output the value feeds: 0 (from NaN) or inf
     assert (bad[~touched.expand_as(bad)] - refb[~touched.expand_as(bad)]).abs().max().item() <= 1e-4
-    good = ops.nhwc_to_nchw(ops.conv2d_nhwc(xbn, wbp, pad=1, tile=22, split_k=1, precision=2, a_scale_exp=2)).cpu()
+    flag.zero_()
+    good = ops.nhwc_to_nchw(ops.conv2d_nhwc(xbn, wbp, pad=1, tile=22, split_k=1, precision=2, a_scale_exp=2, range_flag=flag)).cpu()
+    assert int(flag.item()) == 0
+    for split in (3, -1, -2):                                                          # K-slices report from their partial sums
+        flag.zero_()
+        ops.conv2d_nhwc(xbn, wbp, pad=1, tile=22, split_k=split, precision=2, a_scale_exp=4, range_flag=flag)
+        assert int(flag.item()) == 1, split
     assert (good - refb).abs().max().item() <= 2e-3 * 1.0                            # (values ~100: 5000 * w; f32-level relative error)
 
 

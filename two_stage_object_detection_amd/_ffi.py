@@ -43,7 +43,7 @@ class ConvDesc(Structure):
         ("OH", c_int32), ("OW", c_int32), ("act", c_int32), ("slope", c_float),
         ("res_pitch", c_int32), ("res_off", c_int32), ("tile", c_int32), ("split_k", c_int32), ("precision", c_int32),
         ("c2", c_int32), ("in2_pitch", c_int32), ("in2_off", c_int32), ("stride2", c_int32), ("H2", c_int32), ("W2", c_int32),
-        ("a_scale_exp", c_int32), ("w_scale_exp", c_int32),
+        ("a_scale_exp", c_int32), ("w_scale_exp", c_int32), ("range_flag", c_void_p),
     ]
 
 

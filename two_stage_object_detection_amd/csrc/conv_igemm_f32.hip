@@ -62,6 +62,7 @@ struct ConvParams {
     // `split` K-slices, one workgroup per (tile, slice), partial sums reduced by conv_reduce_kernel
     int dp_tiles, split, ksteps_per_split;
     int sk_q;                     // > 0: balanced schedule (conv_dma_kernel): K-steps per workgroup of the tile-major K-step sequence
+    int *range_flag;              // fp16x2 only, optional: set to 1 by any workgroup that ends its K loop with a non-finite accumulator
     float a_scale, acc_scale;     // fp16x2 arithmetic only: activations are split as a_scale * x (a power of two), the accumulators
                                   // are multiplied by acc_scale = 1 / (a_scale * weight scale) before the epilogue
     int ci_wrap;                  // channels a tap's run of K-steps covers before the next tap: Cin (tap-major), 32 (cmajor)
@@ -1579,6 +1580,18 @@ conv_dma_kernel(const ConvParams p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[0][j][e] *= p.acc_scale;
+        // the range guard: an activation beyond 65504 / a_scale splits into +-inf pieces whose products make EVERY accumulator
+        // it feeds inf or NaN (a zero weight gives 0 * inf = NaN too), so a finite tile proves its inputs were in range; a
+        // non-finite one (also from genuinely non-finite input) raises the caller's flag - the epilogue's branch-free
+        // activation would otherwise turn the NaNs into plausible zeros
+        if (p.range_flag != nullptr) {
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) bad |= !(fabsf(acc[0][j][e]) <= 3.4028234664e38f);
+            if (__any(bad) && lane == 0) atomicOr(p.range_flag, 1);
+        }
     }
 #ifdef TSOD_DIAG_MFMA16
 #pragma unroll
@@ -2057,9 +2070,10 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
     p.part_bytes = (unsigned)(sc.ws_bytes - sc.ticket_bytes);
     TSOD_REQUIRE(sc.ws_bytes < 0xFFFFFFF0ull, TSOD_ERR_UNSUPPORTED);
     hipStream_t s = tsod_stream(stream);
-    p.a_scale = 1.f; p.acc_scale = 1.f;
+    p.a_scale = 1.f; p.acc_scale = 1.f; p.range_flag = nullptr;
     if (d->precision == TSOD_PREC_FP16X2) {
         TSOD_REQUIRE(sc.tile == TSOD_TILE_D128x128_K32, TSOD_ERR_UNSUPPORTED);
+        p.range_flag = d->range_flag;
         p.a_scale = ldexpf(1.f, d->a_scale_exp);
         p.acc_scale = ldexpf(1.f, -(d->a_scale_exp + d->w_scale_exp));
         launch_dma_tile<128, 32, 2, 3, 1, 2>(p, sc.grid, s);

@@ -155,7 +155,7 @@ def _merge_adjacent(segs):
 
 # --------------------------------------------------------------------------- plan
 class ConvStep:
-    __slots__ = ("desc", "args", "name", "flops", "ws_bytes", "pc", "fn", "w_index", "ws_index")
+    __slots__ = ("desc", "args", "name", "flops", "ws_bytes", "pc", "fn", "w_index", "ws_index", "range_flag")
 
     def choose(self, tile: int, split_k: int, precision: int):
         """Pin (tile, K-slice schedule, arithmetic); the weight argument follows the arithmetic (f32 or pre-split bf16x3)."""
@@ -164,6 +164,7 @@ class ConvStep:
         if precision == _ffi.PREC_FP16X2:
             w2, e = weights_fp16x2(self.pc)
             d.a_scale_exp, d.w_scale_exp = FP16X2_A_SCALE_EXP, int(e)
+            d.range_flag = ptr(self.range_flag)                  # the plan's word: PlanOwner.raise_if_error reads it
             self.args[self.w_index] = ptr(w2)
         else:
             self.args[self.w_index] = ptr(weights_bf16x3(self.pc)) if precision == _ffi.PREC_BF16X3 else ptr(self.pc.w)
@@ -182,6 +183,8 @@ class Plan:
         self._ws_slots: list[tuple[list, int, int, int]] = []   # (args, ptr index, size index, bytes)
         self.workspace: torch.Tensor | None = None
         self.graph = None
+        # fp16x2 layers OR 1 into this word when an activation left the arithmetic's range (include/tsod.h: range_flag)
+        self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.flops = 0
 
     # -- building ---------------------------------------------------------------------------
@@ -234,6 +237,7 @@ class Plan:
         self.steps.append([lib().tsod_conv2d_dual_f32 if x2 is not None else lib().tsod_conv2d_f32, args])
         st = ConvStep()
         st.desc, st.args, st.name, st.pc = d, args, name, pc
+        st.range_flag = self.range_flag
         st.fn = self.steps[-1][0]
         st.w_index, st.ws_index = (3, 8) if x2 is not None else (2, 7)
         st.flops = 2 * N * OH * OW * getattr(pc, "cout_real", pc.cout) * pc.kh * pc.kw_logical * pc.cin_src   # algorithmic
@@ -587,6 +591,18 @@ class PlanOwner:
         self.conv_precision = precision
         self.__dict__["_plans"] = OrderedDict()
         return self
+
+    def raise_if_error(self):
+        """Surface a range violation of the fp16x2 arithmetic in any plan of this owner (one device sync per plan that has
+        fp16x2 layers): the forward that set it produced garbage in the layers concerned."""
+        for plan in list(self.__dict__.get("_plans", {}).values()):
+            flag = getattr(plan, "range_flag", None)
+            if flag is not None and any(int(st.desc.precision) == _ffi.PREC_FP16X2 for st in plan.conv_steps) and int(flag.item()) != 0:
+                with torch.inference_mode():
+                    flag.zero_()
+                raise TsodError("fp16x2: a conv layer ended with non-finite accumulators - an activation beyond +-"
+                                f"{65504 // (1 << FP16X2_A_SCALE_EXP)} (or non-finite input); its outputs are garbage. Re-tune with "
+                                "precisions=(0, 1) (bf16x3 / f32) for this model")
 
     def _init_plan_owner(self):
         self.__dict__["_plans"] = OrderedDict()

@@ -177,7 +177,8 @@ def _w3_for(w_packed: torch.Tensor) -> torch.Tensor:
 
 def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_logical=None, scale=None, shift=None,
                 residual=None, act=ACT_NONE, slope=0.0, segs=None, out=None, out_off=0, tile=0, split_k=0,
-                precision=0, x2=None, stride2=1, x2_off=0, w3=None, a_scale_exp=4, w2=None, w_scale_exp=None) -> torch.Tensor:
+                precision=0, x2=None, stride2=1, x2_off=0, w3=None, a_scale_exp=4, w2=None, w_scale_exp=None,
+                range_flag=None) -> torch.Tensor:
     """Implicit-GEMM convolution on an NHWC tensor [N,H,W,P].  ``w_packed`` is [Cout,KH,KW,Cin]
     (see pack_conv_weight); ``kw_logical`` is the filter width before zero-tap padding (it fixes OW).
     ``segs`` = [(channel offset, length), ...] inside the P-wide pixel (default: the first Cin
@@ -188,7 +189,8 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
     ``w3``: the pre-split bf16x3 image of ``w_packed`` (pack_conv_weight_bf16x3) when the caller keeps one; used with
     ``precision`` = bf16x3 instead of the wrapper's own cache.  ``precision`` = fp16x2 (experimental): activations are split as
     2^``a_scale_exp`` * x (|that| must stay below 65504), ``w2`` / ``w_scale_exp`` = the fp16x2 weight image and the exponent it
-    was packed with (made on the spot from ``w_packed`` when not given)."""
+    was packed with (made on the spot from ``w_packed`` when not given); ``range_flag``: an int32 device word the launch sets to 1
+    when an activation left that range."""
     require_cuda(x, "conv2d")
     assert x.is_contiguous() and w_packed.is_contiguous()
     N, H, W, P = x.shape
@@ -215,6 +217,7 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
             w_scale_exp = fp16x2_weight_scale_exp(w_packed)
             w2 = pack_conv_weight_fp16x2(w_packed, w_scale_exp)
         d.a_scale_exp, d.w_scale_exp = int(a_scale_exp), int(w_scale_exp)
+        d.range_flag = ptr(range_flag)                            # optional int32 [1] device tensor: 1 = an activation left the range
     ws_bytes = lib().tsod_conv2d_workspace_bytes(byref(d))
     ws = CONV_ARENA.get(x.device, ws_bytes) if ws_bytes else None
     # bf16x3 / fp16x2 read their pre-split weight images
