@@ -35,7 +35,8 @@ Every timed region (exactly K steps between barrier + synchronize on both sides,
                      (three exact bf16 pieces per operand, six bf16 MFMAs per f32 product: peak 2516.8 / 6 = 419.5 TFLOP/s
                      f32-equivalent).  achieved = algorithmic f32 conv FLOPs / kernel time; peak = the FLOP-weighted
                      (harmonic) peak of the layers' arithmetics, so frac = sum of the layers' ideal matrix-pipe times /
-                     measured time.  roofline_f32_mfma is the same measurement with every layer pinned to the f32-MFMA
+                     measured time.  roofline_bf16x3 is the same measurement with a tile table tuned among f32 and bf16x3 only
+                     (no fp16x2: the arithmetic of rounds 2-3); roofline_f32_mfma with every layer pinned to the f32-MFMA
                      kernels (the number comparable with round 1).
   roofline.traffic : HBM bytes per conv launch from FETCH_SIZE / WRITE_SIZE, collected by two short `rocprofv3 --pmc`
                      child runs of this script (rank 0, N = 1; --no-pmc skips them).
@@ -83,11 +84,13 @@ def parse(argv=None):
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--num-classes", type=int, default=80)
     ap.add_argument("--no-autotune", action="store_true")
-    ap.add_argument("--precision", default="auto", choices=("f32", "bf16x3", "auto", "fp16x2"), help="arithmetic of the conv GEMMs: f32 = "
-                    "v_mfma_f32_32x32x2_f32; bf16x3 = three exact bf16 pieces per operand on v_mfma_f32_32x32x16_bf16 "
-                    "(f32-accurate, gated by the same parity suite); auto = the autotuner picks per layer; fp16x2 = auto with the "
-                    "EXPERIMENTAL third arithmetic among the candidates (two fp16 pieces of 16 x per operand, three products: "
-                    "f32-accurate while |x| < 4094 - opt-in, not the default line)")
+    ap.add_argument("--precision", default="auto", choices=("f32", "bf16x3", "auto", "auto-bf16x3", "fp16x2"), help="arithmetic of the "
+                    "conv GEMMs: f32 = v_mfma_f32_32x32x2_f32; bf16x3 = three exact bf16 pieces per operand, six products on "
+                    "v_mfma_f32_32x32x16_bf16; fp16x2 (for the layers whose tile has it, candidates like auto) = two fp16 pieces of "
+                    "16 x per operand, three products on v_mfma_f32_32x32x16_f16 - all three f32-accurate and gated by the same "
+                    "parity suite, fp16x2 while |x| < 4094 (beyond it the launch raises a range flag that "
+                    "FasterRCNN.raise_if_error() surfaces); auto (default) = the autotuner picks per layer among all three; "
+                    "auto-bf16x3 = among f32 and bf16x3 only (rounds 2-3)")
     ap.add_argument("--autotune-concurrent", type=int, default=None, help="copies of a candidate in flight on separate streams while "
                     "the in-flight tile table is tuned (default: --in-flight, i.e. 4: measured 697 -> 754 images/s on one box "
                     "against tuning with 2 copies; 6 and 8 are no better)")
@@ -487,7 +490,7 @@ def main(argv=None):
                                            # there and only lengthens the tuning pass (8 ranks tune at once in the N > 1 runs)
         tiles_loaded = bool(args.tiles_file and os.path.exists(args.tiles_file))
         t_tune = time.perf_counter()
-        precs = {"f32": (0,), "bf16x3": (1,), "auto": (0, 1), "fp16x2": (0, 1, 2)}[args.precision]
+        precs = {"f32": (0,), "bf16x3": (1,), "auto-bf16x3": (0, 1), "auto": (0, 1, 2), "fp16x2": (0, 1, 2)}[args.precision]
         if tiles_loaded:
             tiles = json.load(open(args.tiles_file))
         elif not args.no_autotune and world > 1:
@@ -567,6 +570,24 @@ def main(argv=None):
                        "kernel_ms_per_forward": round(ms32, 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
                        "note": "the same conv launches with every layer pinned to the f32-MFMA kernels (one pass in forward order, "
                                "HIP events); not the timed path when --precision auto picks bf16x3"}
+        # ---- the same with the candidates of rounds 2-3 (f32 / bf16x3 per layer, no fp16x2): what the third arithmetic buys
+        bf_leg = None
+        if world == 1 and not args.no_autotune and not args.no_graph and 2 in precs and not (tiles_loaded and "bf16x3" not in tiles):
+            if "bf16x3" not in tiles:
+                plan.autotune(verbose=False, splits=splits, concurrent=1, precisions=(0, 1), in_sequence=args.autotune_in_sequence)
+                tiles["bf16x3"] = plan.export_tiles()
+                if args.tiles_file and rank == 0:
+                    json.dump(tiles, open(args.tiles_file, "w"))
+            plan.import_tiles(tiles["bf16x3"])
+            msb = conv_sequence_time(plan)
+            flb = sum(st.flops for st in plan.conv_steps)
+            prb = [int(st.desc.precision) for st in plan.conv_steps]
+            idb = sum(st.flops / ((BF16X3_PEAK_TFLOPS if pr == 1 else F32_MFMA_PEAK_TFLOPS) * 1e12) * 1e3 for st, pr in zip(plan.conv_steps, prb))
+            bf_leg = {"bound": "mfma", "achieved": round(flb / (msb * 1e-3) / 1e12, 3), "peak": round(flb / (idb * 1e-3) / 1e12, 1),
+                      "unit": "TFLOP/s", "frac": round(idb / msb, 4), "kernel_ms_per_forward": round(msb, 4),
+                      "dtype": "bf16x3 / f32 MFMA per layer (no fp16x2)",
+                      "note": "the same conv launches with a tile table tuned among f32 and bf16x3 only (one pass in forward order, HIP "
+                              "events): the arithmetic of rounds 2-3, not the timed path when fp16x2 is among the candidates"}
         # ---- schedule 1: strictly serial (one graph, one stream) + the per-kernel roofline that belongs to it
         plan.import_tiles(tiles["serial"])
         conv_ms = conv_event_times(plan)
@@ -697,6 +718,8 @@ def main(argv=None):
                                   + (" (rank 0 tunes, the others wait for its broadcast)" if world > 1 else "")}
         if f32_leg is not None:
             line["roofline_f32_mfma"] = f32_leg
+        if bf_leg is not None:
+            line["roofline_bf16x3"] = bf_leg
         if check is not None:
             line["check"] = check
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -410,6 +410,7 @@ class Plan:
             results = self._refine_in_sequence([c[:in_sequence] for c in shortlist], results, big, reps=5, verbose=verbose)
         del big, bigs
         self.finalize()
+        self.range_flag.zero_()      # (timing launches ran on whatever the pooled buffers held: not a forward's verdict)
         return results
 
     def _refine_in_sequence(self, shortlist, results, big, reps, verbose):
@@ -557,6 +558,8 @@ def refine_in_flight(plans, shortlist, rounds: int = 4, verbose: bool = False):
         pl.finalize()
     if verbose:
         print(f"  in flight: {changed} of {L} picks changed; conv time per forward with {n} staggered streams {base / rounds / n * 1e3:.1f} us")
+    for pl in plans:
+        pl.range_flag.zero_()                                        # (see Plan.autotune)
     return plans[0].export_tiles()
 
 
