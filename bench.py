@@ -165,6 +165,7 @@ def conv_event_times(plan, reps=5):
         e1.record()
         e1.synchronize()
         out.append(e0.elapsed_time(e1) / reps)
+    plan.range_flag.zero_()      # (these launches ran on whatever the pooled buffers held, not on a forward's activations)
     return out
 
 
@@ -185,7 +186,9 @@ def conv_sequence_time(plan, reps=10):
             st.fn(*st.args, s)
     e1.record()
     e1.synchronize()
-    return e0.elapsed_time(e1) / reps
+    ms = e0.elapsed_time(e1) / reps
+    plan.range_flag.zero_()      # (see conv_event_times)
+    return ms
 
 
 def cpu_baseline(sd, backbone, x_cpu, reps):
@@ -490,6 +493,13 @@ def main(argv=None):
                                            # there and only lengthens the tuning pass (8 ranks tune at once in the N > 1 runs)
         tiles_loaded = bool(args.tiles_file and os.path.exists(args.tiles_file))
         t_tune = time.perf_counter()
+        if not tiles_loaded and not args.no_autotune:
+            # bring the chip into the state the tuned kernels will run in before anything is timed: on a box that has just started,
+            # the first candidates of every layer see boost clocks the later ones do not (the arithmetics are timed one after the
+            # other), and the serial table came out 0.2 ms slower on the first run of a box than on the next ones
+            t_w = time.perf_counter()
+            while time.perf_counter() - t_w < 1.5:
+                conv_sequence_time(plan, reps=20)
         precs = {"f32": (0,), "bf16x3": (1,), "auto-bf16x3": (0, 1), "auto": (0, 1, 2), "fp16x2": (0, 1, 2)}[args.precision]
         if tiles_loaded:
             tiles = json.load(open(args.tiles_file))
