@@ -674,8 +674,8 @@ def main(argv=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if n_bf + n_h2 == 0 else "f32 storage/accumulate; conv products as bf16x3 (3 exact bf16 pieces per operand, "
                                               f"6 bf16 MFMAs per product) in {n_bf} of {len(precs)} conv layers, "
-                                              + (f"as fp16x2 (EXPERIMENTAL, opt-in: 2 fp16 pieces of 16 x per operand, 3 fp16 MFMAs per "
-                                                 f"product, f32-accurate while |x| < 4094) in {n_h2}, " if n_h2 else "")
+                                              + (f"as fp16x2 (2 fp16 pieces of 16 x per operand, 3 fp16 MFMAs per product: f32-accurate while "
+                                                 f"|x| < 4094, which every launch checks - a violation raises) in {n_h2}, " if n_h2 else "")
                                               + "f32 MFMA in the rest",
             "data": "synthetic",
             "config": {"workload": f"Full Faster R-CNN {args.backbone} inference forward, batch={B} per GPU, "

@@ -147,7 +147,7 @@ def test_detector_after_the_in_sequence_autotune(dev, r50):
 
 
 def test_detector_with_the_fp16x2_arithmetic_among_the_candidates(dev, r50):
-    """`bench.py --precision fp16x2` (EXPERIMENTAL, opt-in): the third arithmetic - two fp16 pieces of 16 x per operand, three
+    """`bench.py --precision auto` since the end of round 3: the third arithmetic - two fp16 pieces of 16 x per operand, three
     piece products per f32 product on v_mfma_f32_32x32x16_f16 - competes per layer; then the same with every layer that can
     take it FORCED onto it (so the gate does not depend on what the clock picked).  Same bars as every other tile table: the
     oracle's RoIs, no unmatched row, no class mismatch.  (The synthetic trunk's activations reach abs-max ~100: inside the
