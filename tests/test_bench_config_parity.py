@@ -102,8 +102,8 @@ def test_detector_after_plan_autotune_and_through_the_serving_path(dev, r50):
         assert all(len(c) == 3 and c[2] in (0, 1) for c in heads)
         tuned = plan.export_tiles()
         assert len(res) == len(plan.conv_steps) == 49          # 53 convs, the four projection shortcuts ride in their conv3's GEMM
-        from two_stage_object_detection_amd._ffi import BF16X3_TILE_IDS, TILE_IDS
-        assert all(t in ((22,) if p == 2 else BF16X3_TILE_IDS if p else TILE_IDS) and p in (0, 1, 2) for _, t, _, p in tuned)
+        from two_stage_object_detection_amd._ffi import BF16X3_TILE_IDS, FP16X2_TILE_IDS, TILE_IDS
+        assert all(t in (FP16X2_TILE_IDS if p == 2 else BF16X3_TILE_IDS if p else TILE_IDS) and p in (0, 1, 2) for _, t, _, p in tuned)
         got = [o.cpu() for o in model(xg)]
         model.raise_if_error()
         rep = compare_detector_outputs(got, ref)

@@ -578,7 +578,7 @@ def test_conv_dual_source_is_the_sum_of_two_convs(ops, dev, C1, C2, Cout, stride
 @pytest.mark.parametrize("N,Cin,Cout,H,W,k,res", [(1, 256, 256, 50, 84, 3, False), (2, 1024, 256, 25, 21, 1, False), (1, 512, 2048, 13, 21, 1, True),
                                                   (1, 64, 64, 37, 41, 3, True), (1, 128, 96, 19, 23, 3, False)])
 def test_conv_fp16x2_matches_the_f64_convolution(ops, dev, N, Cin, Cout, H, W, k, res):
-    """TSOD_PREC_FP16X2 (experimental; tile d128x128k32): two fp16 pieces of 16 x per operand, three piece products per f32
+    """TSOD_PREC_FP16X2 (tile d128x128k32 and the register-staged family): two fp16 pieces of 16 x per operand, three piece products per f32
     product.  Held to the bf16x3 / f32 bar against the f64 CPU convolution under every K schedule, and to <= 2x the error of the
     bf16x3 form of the same launch (measured: below it)."""
     g = torch.Generator().manual_seed(5)
@@ -593,17 +593,19 @@ def test_conv_fp16x2_matches_the_f64_convolution(ops, dev, N, Cin, Cout, H, W, k
     xn, wp = ops.nchw_to_nhwc(x.to(dev)), ops.pack_conv_weight(w.to(dev))
     rn = ops.nchw_to_nhwc(r.to(dev)) if res else None
     tol = 3e-6 * math.sqrt(k * k * Cin) + 1e-5
+    from two_stage_object_detection_amd._ffi import FP16X2_TILE_IDS
     e3 = (ops.nhwc_to_nchw(ops.conv2d_nhwc(xn, wp, pad=k // 2, tile=22, split_k=1, precision=1, residual=rn, act=1, slope=0.25)).cpu() - ref).abs().max().item()
-    for split in (1, 3, -1, -2):
-        out = ops.conv2d_nhwc(xn, wp, pad=k // 2, tile=22, split_k=split, precision=2, residual=rn, act=1, slope=0.25, a_scale_exp=4)
-        e = (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item()
-        assert e <= tol and e <= 2 * e3 + 1e-7, (split, e, e3, tol)
+    for tile in FP16X2_TILE_IDS:                                 # the LDS-DMA tile and the register-staged family
+        for split in (1, 3, -1) + ((-2,) if tile == 22 else ()):
+            out = ops.conv2d_nhwc(xn, wp, pad=k // 2, tile=tile, split_k=split, precision=2, residual=rn, act=1, slope=0.25, a_scale_exp=4)
+            e = (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item()
+            assert e <= tol and e <= 2 * e3 + 1e-7, (tile, split, e, e3, tol)
 
 
 def test_conv_fp16x2_second_source_range_and_gates(ops, dev):
     """The rest of the fp16x2 contract: the stacked-K form with a second source (a bottleneck's conv3 + projection shortcut)
-    matches the two f64 convolutions added up; only tile d128x128k32 takes the arithmetic (others: TSOD_ERR_UNSUPPORTED,
-    TSOD_TILE_AUTO resolves to it); what happens beyond the range (|x| >= 65504 / 2^a_scale_exp) is pinned down as it IS: the
+    matches the two f64 convolutions added up; the register-staged bf16x3 tiles and d128x128k32 take the arithmetic (others:
+    TSOD_ERR_UNSUPPORTED, TSOD_TILE_AUTO resolves among them), concatenated channel segments included; what happens beyond the range (|x| >= 65504 / 2^a_scale_exp) is pinned down as it IS: the
     pieces overflow to +-inf, their products cancel to NaN, and the branch-free activation of the epilogue maps NaN to 0 - the
     outputs the value feeds come out 0, everything else is untouched - and the launch raises desc.range_flag (every workgroup
     checks its accumulators behind the K loop: a finite tile proves its inputs were in range), under every K schedule; a
@@ -624,9 +626,22 @@ def test_conv_fp16x2_second_source_range_and_gates(ops, dev):
         assert (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item() <= tol, split
     out = ops.conv2d_nhwc(yn, w, segs=[(0, C1)], precision=2, x2=xn)                  # AUTO
     assert (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item() <= tol
-    for tile in (3, 14, 17, 18, 21):
+    for tile in (1, 2, 12, 17, 18, 21):                                            # f32-only tiles and the other LDS-DMA shapes
         with pytest.raises(TsodError, match="unsupported|UNSUPPORTED"):
             ops.conv2d_nhwc(yn, w, segs=[(0, C1)], tile=tile, split_k=1, precision=2, x2=xn)
+    for tile in (3, 14, 16):                                                       # the register-staged family takes the second source too
+        out = ops.conv2d_nhwc(yn, w, segs=[(0, C1)], tile=tile, split_k=1, precision=2, x2=xn)
+        assert (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item() <= tol, tile
+    # concatenated channel segments and a K that is no multiple of the K-step (HarDNet's layers): register-staged tiles only
+    g2 = torch.Generator().manual_seed(37)
+    xs = torch.randn(2, 60, 9, 11, generator=g2)
+    ws = torch.randn(20, 44, 1, 1, generator=g2) / math.sqrt(44)
+    segs = [(36, 24), (4, 20)]
+    refs = F.conv2d(torch.cat([xs[:, 36:60], xs[:, 4:24]], dim=1).double(), ws.double()).float()
+    xsn, wsp = ops.nchw_to_nhwc(xs.to(dev)), ops.pack_conv_weight(ws.to(dev))
+    for tile in (3, 8, 14):
+        out = ops.conv2d_nhwc(xsn, wsp, segs=segs, tile=tile, split_k=1, precision=2)
+        assert (ops.nhwc_to_nchw(out).cpu() - refs).abs().max().item() <= 3e-6 * math.sqrt(44) + 1e-5, tile
     # range: one activation of 5000 with a_scale_exp = 4 (16 * 5000 > 65504)
     xb = torch.randn(1, 64, 9, 9, generator=g)
     xb[0, 3, 4, 4] = 5000.0

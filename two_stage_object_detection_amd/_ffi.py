@@ -23,9 +23,9 @@ TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "64x128", 5: 
 TILE_IDS = tuple(range(1, 17))
 PREC_F32, PREC_BF16X3, PREC_FP16X2 = 0, 1, 2
 PREC_NAMES = {0: "f32", 1: "bf16x3", 2: "fp16x2"}
-DMA_TILE_IDS = (17, 18, 19, 20, 21, 22)
-FP16X2_TILE_IDS = (22,)         # the experimental fp16x2 arithmetic exists for d128x128k32 only                             # bf16x3 through LDS-DMA: one channel segment, Cin % 16 / % 32 == 0, bf16x3 ONLY
+DMA_TILE_IDS = (17, 18, 19, 20, 21, 22)                             # bf16x3 through LDS-DMA: one channel segment, Cin % 16 / % 32 == 0, bf16x3 ONLY
 BF16X3_TILE_IDS = (3, 8, 9, 10, 14, 15, 16) + DMA_TILE_IDS   # tiles that exist as bf16x3 variants (include/tsod.h)
+FP16X2_TILE_IDS = tuple(t for t in BF16X3_TILE_IDS if t not in DMA_TILE_IDS or t == 22)   # fp16x2: the register-staged bf16x3 tiles + d128x128k32
 
 
 class TsodError(RuntimeError):

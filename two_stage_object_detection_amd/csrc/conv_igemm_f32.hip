@@ -42,6 +42,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kPatchLD = 36;  // row pitch (floats) of the epilogue transpose patches
 
@@ -130,6 +131,16 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &h, uns
     m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
     f32x2 r2 = {r1.x - __uint_as_float(m << 16), r1.y - __uint_as_float(m & 0xFFFF0000u)};
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+
+// fp16x2 (TSOD_PREC_FP16X2): two elements as fp16 pieces of sc * x: hi = rne(sc x), lo = rne(sc x - hi) (the subtraction is exact);
+// the plain-code form of the split (the asm statements of conv_dma_kernel's loop compute the same bits)
+__device__ __forceinline__ void split2_pair(float x0, float x1, float sc, unsigned &h, unsigned &l) {
+    const float xs0 = sc * x0, xs1 = sc * x1;
+    const _Float16 h0 = (_Float16)xs0, h1 = (_Float16)xs1;
+    const _Float16 l0 = (_Float16)(xs0 - (float)h0), l1 = (_Float16)(xs1 - (float)h1);
+    h = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    l = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
 }
 
 // channel index inside the (concatenated) Cin -> offset inside the input pixel (select chain, no branches)
@@ -513,7 +524,8 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     // on every write, a third of the LDS-active cycles), and slot' = slot ^ ((row / rows per 256 B) & (slots - 1)) gives the
     // 16 rows of every read group 16 distinct slots of the 256-byte line.  Row pitch counted in floats here.
     constexpr int kBK = BK, kLDK = PREC ? BK / 2 : BK + 4;
-    constexpr int kPlanes = PREC ? 3 : 1;
+    constexpr int NPL = PREC == 2 ? 2 : 3;             // pieces per operand of the split arithmetics (bf16x3: 3, fp16x2: 2)
+    constexpr int kPlanes = PREC ? NPL : 1;
     constexpr int kSlots = BK / 8;                     // 16-byte slots (8 bf16) per bf16x3 row
     constexpr int kRowsPerLine = 256 / (kSlots * 16) > 0 ? 256 / (kSlots * 16) : 1;   // rows sharing one 256-byte bank line
     auto swz = [](int row) { return (row / kRowsPerLine) & (kSlots - 1); };            // slot' = slot ^ swz(row)
@@ -527,7 +539,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     // bf16 (48 bytes per 8 k), so a thread moves whole 8-k groups: three 16-byte loads, three ds_write_b128, no VALU.
     constexpr int GPR = BK / 8;                        // 8-k groups per row and K-step
     constexpr int B_TASKS = (BN * GPR + THREADS - 1) / THREADS;
-    constexpr int B_ROWS = PREC ? 3 * B_TASKS : BN / RPP;   // staging registers (16 bytes each) for B
+    constexpr int B_ROWS = PREC ? NPL * B_TASKS : BN / RPP;   // staging registers (16 bytes each) for B
     constexpr int STAGE = kPlanes * (BM + BN) * kLDK;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
     constexpr int PATCHES = (THREADS / 64) * 32 * kPatchLD;                      // epilogue transpose patches, one per wave
@@ -589,7 +601,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
             b_base[i] = n < p.Cout ? (unsigned)n * (unsigned)p.K * 4u : kOOB;
         } else {
             const int t = tid + THREADS * i, n = n0 + t / GPR;
-            b_base[i] = (t < BN * GPR && n < p.Cout) ? (unsigned)n * (unsigned)kgroups * 48u + (unsigned)(t % GPR) * 48u : kOOB;
+            b_base[i] = (t < BN * GPR && n < p.Cout) ? (unsigned)n * (unsigned)kgroups * (16u * NPL) + (unsigned)(t % GPR) * (16u * NPL) : kOOB;
         }
     }
 
@@ -634,11 +646,11 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
 #pragma unroll
                 for (int i = 0; i < B_ROWS; ++i) rb[i] = buffer_load4(rs_w, b_base[i] != kOOB ? b_base[i] + (unsigned)k * 4u : kOOB);
             } else {
-                const unsigned goff = (unsigned)kq * (unsigned)(GPR * 48);
+                const unsigned goff = (unsigned)kq * (unsigned)(GPR * 16 * NPL);
 #pragma unroll
                 for (int i = 0; i < B_TASKS; ++i) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) rb[3 * i + q] = buffer_load4(rs_w, b_base[i] != kOOB ? b_base[i] + goff + 16u * q : kOOB);
+                    for (int q = 0; q < NPL; ++q) rb[NPL * i + q] = buffer_load4(rs_w, b_base[i] != kOOB ? b_base[i] + goff + 16u * q : kOOB);
                 }
             }
             u_ci += kBK;
@@ -664,12 +676,12 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i) rb[i] = buffer_load4(rs_w, (kin && b_base[i] != kOOB) ? b_base[i] + (unsigned)k * 4u : kOOB);
         } else {
-            const unsigned goff = (unsigned)kq * (unsigned)(GPR * 48);
+            const unsigned goff = (unsigned)kq * (unsigned)(GPR * 16 * NPL);
 #pragma unroll
             for (int i = 0; i < B_TASKS; ++i) {
                 const bool ok = b_base[i] != kOOB && kq * GPR + (tid + THREADS * i) % GPR < kgroups;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) rb[3 * i + q] = buffer_load4(rs_w, ok ? b_base[i] + goff + 16u * q : kOOB);
+                for (int q = 0; q < NPL; ++q) rb[NPL * i + q] = buffer_load4(rs_w, ok ? b_base[i] + goff + 16u * q : kOOB);
             }
         }
         k += kBK;
@@ -682,12 +694,18 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
             *reinterpret_cast<float4 *>(base + row * kLDK + c4) = v;
         } else {
             unsigned h[2], m[2], l[2];
-            split3_pair(v.x, v.y, h[0], m[0], l[0]);
-            split3_pair(v.z, v.w, h[1], m[1], l[1]);
+            if constexpr (PREC == 2) {
+                split2_pair(v.x, v.y, p.a_scale, h[0], l[0]);
+                split2_pair(v.z, v.w, p.a_scale, h[1], l[1]);
+                m[0] = m[1] = 0;
+            } else {
+                split3_pair(v.x, v.y, h[0], m[0], l[0]);
+                split3_pair(v.z, v.w, h[1], m[1], l[1]);
+            }
             unsigned char *b = reinterpret_cast<unsigned char *>(base) + row * (kLDK * 4) + (((c4 >> 3) ^ swz(row)) << 4) + (c4 & 4) * 2;
             *reinterpret_cast<uint2 *>(b) = make_uint2(h[0], h[1]);
-            *reinterpret_cast<uint2 *>(b + BM * (kLDK * 4)) = make_uint2(m[0], m[1]);
-            *reinterpret_cast<uint2 *>(b + 2 * BM * (kLDK * 4)) = make_uint2(l[0], l[1]);
+            if constexpr (PREC == 1) *reinterpret_cast<uint2 *>(b + BM * (kLDK * 4)) = make_uint2(m[0], m[1]);
+            *reinterpret_cast<uint2 *>(b + (NPL - 1) * BM * (kLDK * 4)) = make_uint2(l[0], l[1]);
         }
     };
     auto store_b = [&](int buf, const float4(&rb)[B_ROWS]) {
@@ -701,9 +719,9 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
                 const int t = tid + THREADS * i;
                 if (t < BN * GPR) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q)
+                    for (int q = 0; q < NPL; ++q)
                         *reinterpret_cast<float4 *>(base + q * BN * (kLDK * 4) + (t / GPR) * (kLDK * 4) +
-                                                    (((t % GPR) ^ swz(t / GPR)) << 4)) = rb[3 * i + q];
+                                                    (((t % GPR) ^ swz(t / GPR)) << 4)) = rb[NPL * i + q];
                 }
             }
         }
@@ -736,8 +754,8 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     //   the LDS writes of step kt+1 are issued behind the first MFMA group and complete under the rest.
     auto kstep = [&](int buf, bool do_load, float4(&lra)[A_ROWS], float4(&lrb)[B_ROWS], bool do_store,
                      const float4(&sra)[A_ROWS], const float4(&srb)[B_ROWS]) {
-        if constexpr (PREC == 1) {
-            // bf16x3: per 16-k chunk a lane reads ONE ds_read_b128 per plane and 32-row block = 8 consecutive bf16 of row
+        if constexpr (PREC != 0) {
+            // bf16x3 / fp16x2: per 16-k chunk a lane reads ONE ds_read_b128 per plane and 32-row block = 8 consecutive bf16 of row
             // (lane & 31) at k = 16 * chunk + 8 * (lane >> 5); six MFMAs per (A block, B block), smallest products first
             constexpr int ROW_B = kLDK * 4, CHUNKS = kBK / 16;
             // logical slot of chunk c for this lane = 2c + (lane >> 5); physical = that ^ swz(row), and swz(row) depends only on
@@ -749,17 +767,17 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
             // two fragment sets: chunk c + 1 is read into the other set BEFORE chunk c's MFMAs are issued, so its LDS latency
             // lies under them (with one set the compiler re-reads into registers an MFMA has just consumed and the next MFMA
             // waits for LDS three times per chunk)
-            bf16x8 fa[2][TM][3], fb[2][TN][3];
+            bf16x8 fa[2][TM][NPL], fb[2][TN][NPL];
             auto load_frags = [&](int c, int set) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q)
+                    for (int q = 0; q < NPL; ++q)
                         fa[set][i][q] = *reinterpret_cast<const bf16x8 *>(As + q * BM * ROW_B + i * 32 * ROW_B + (((2 * c) ^ x0) << 4));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q)
+                    for (int q = 0; q < NPL; ++q)
                         fb[set][j][q] = *reinterpret_cast<const bf16x8 *>(Bs + q * BN * ROW_B + j * 32 * ROW_B + (((2 * c) ^ x0) << 4));
             };
             load_frags(0, 0);
@@ -770,15 +788,22 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
                 if (c + 1 < CHUNKS) load_frags(c + 1, cur ^ 1);
                 // six piece products per (A block, B block), smallest first; the product loop is OUTSIDE the block loops so that
                 // consecutive MFMAs write different accumulators wherever the wave owns more than one 32x32 block
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0};          // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
-                constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+                // (fp16x2: lo*hi, hi*lo, hi*hi on the fp16 instruction)
+                constexpr int NQ = PREC == 2 ? 3 : 6;
+                constexpr int PA[6] = {PREC == 2 ? 1 : 2, 0, PREC == 2 ? 0 : 1, 1, 0, 0};          // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+                constexpr int PB[6] = {0, PREC == 2 ? 1 : 2, PREC == 2 ? 0 : 1, 0, 1, 0};
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i][PA[q]], fb[cur][j][PB[q]], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j) {
+                            if constexpr (PREC == 2)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[cur][i][PA[q]]),
+                                                                                   __builtin_bit_cast(f16x8, fb[cur][j][PB[q]]), acc[i][j], 0, 0, 0);
+                            else
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i][PA[q]], fb[cur][j][PB[q]], acc[i][j], 0, 0, 0);
+                        }
                 if (do_store) {                       // the next step's split + LDS writes ride behind this chunk's MFMAs
                     if (c == 0) {
 #pragma unroll
@@ -870,6 +895,19 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     }
 #endif
     const SliceMap sm = {z, p.split, tile_id - p.dp_tiles, -1, 0, 0};
+    if constexpr (PREC == 2) {                                   // fp16x2: back to x . w, and the range guard (conv_dma_kernel has the same)
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    acc[i][j][e] *= p.acc_scale;
+                    bad |= !(fabsf(acc[i][j][e]) <= 3.4028234664e38f);
+                }
+        if (p.range_flag != nullptr && __any(bad) && lane == 0) atomicOr(p.range_flag, 1);
+    }
     // (two slices' slabs in flight per round trip of the combine where a thread holds few quads: 64x64 tiles; one elsewhere - registers)
     conv_epilogue<BM, BN, WM, WN, THREADS, (BM * BN / 4 / THREADS <= 4) ? 2 : 1>(p, acc, smem, tid, wm, wn, m0, n0, sm);
 }
@@ -1017,15 +1055,6 @@ __device__ __forceinline__ void gap2_b(f32x16 &c, const bf16x8 &a, const bf16x8 
                  "ds_read_b128 %4, %11 offset:%12"
                  : "+v"(c), "=&v"(r0), "=&v"(r1), "=&v"(l), "=&v"(rd) : "v"(a), "v"(b), "v"(xs0), "v"(xs1), "v"(t0), "v"(t1), "v"(addr), "n"(OFF) : "memory");
 }
-// the same split in plain code (the prologue's first stage): bit-identical to the statements above (rne both times)
-__device__ __forceinline__ void split2_pair(float x0, float x1, float sc, unsigned &h, unsigned &l) {
-    const float xs0 = sc * x0, xs1 = sc * x1;
-    const _Float16 h0 = (_Float16)xs0, h1 = (_Float16)xs1;
-    const _Float16 l0 = (_Float16)(xs0 - (float)h0), l1 = (_Float16)(xs1 - (float)h1);
-    h = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-    l = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
-}
-
 #ifdef TSOD_DIAG_MFMA16
 // timing probe only (make mfma16; wrong results by design): every v_mfma_f32_32x32x16_bf16 of the K loop replaced by TWO
 // v_mfma_f32_16x16x32_bf16 on the same operand registers (the same matrix-pipe cycles and FLOPs, the other shape's register
@@ -1734,6 +1763,9 @@ const TileInfo kTiles[TSOD_TILE_COUNT] = {
 // bf16x3 = 1: the tile also exists as a bf16x3 variant (three bf16 planes per operand fit the 64 KB of static LDS)
 
 // workgroups per CU: the f32 figure (VGPR / LDS bound), for bf16x3 additionally capped by its larger LDS footprint
+// tiles that exist in the fp16x2 arithmetic: the register-staged bf16x3 tiles and d128x128k32
+bool fp16x2_tile(int t) { return t == TSOD_TILE_D128x128_K32 || (kTiles[t].bf16x3 && !kTiles[t].dma); }
+
 int residency(int tile, int prec) {
     const TileInfo &t = kTiles[tile];
     if (!prec) return t.resident;
@@ -1762,8 +1794,8 @@ int validate(const tsod_conv2d_desc *d) {
     TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->precision == TSOD_PREC_BF16X3 || d->precision == TSOD_PREC_FP16X2, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->tile == TSOD_TILE_AUTO || kTiles[d->tile].bf16x3, TSOD_ERR_UNSUPPORTED);
     TSOD_REQUIRE(d->precision != TSOD_PREC_F32 || d->tile == TSOD_TILE_AUTO || !kTiles[d->tile].dma, TSOD_ERR_UNSUPPORTED);
-    if (d->precision == TSOD_PREC_FP16X2) {                       // (experimental: the 128x128 / 32-k LDS-DMA tile only)
-        TSOD_REQUIRE(d->tile == TSOD_TILE_AUTO || d->tile == TSOD_TILE_D128x128_K32, TSOD_ERR_UNSUPPORTED);
+    if (d->precision == TSOD_PREC_FP16X2) {                       // (the register-staged bf16x3 tiles and the 128x128 / 32-k LDS-DMA tile)
+        TSOD_REQUIRE(d->tile == TSOD_TILE_AUTO || fp16x2_tile(d->tile), TSOD_ERR_UNSUPPORTED);
         TSOD_REQUIRE(d->a_scale_exp >= -24 && d->a_scale_exp <= 24 && d->w_scale_exp >= -40 && d->w_scale_exp <= 40, TSOD_ERR_INVALID_ARG);
     }
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
@@ -1939,7 +1971,7 @@ Sched resolve(const tsod_conv2d_desc *d) {
         if (d->tile != TSOD_TILE_AUTO && d->tile != t) continue;
         if (d->precision && !kTiles[t].bf16x3) continue;
         if (!d->precision && kTiles[t].dma) continue;
-        if (d->precision == TSOD_PREC_FP16X2 && t != TSOD_TILE_D128x128_K32) continue;
+        if (d->precision == TSOD_PREC_FP16X2 && !fp16x2_tile(t)) continue;
         if (!tile_ok_for(d, t)) continue;        // (also an explicitly named tile: the caller gets TSOD_ERR_UNSUPPORTED)
         if (d->split_k != 0) {
             const Sched s = make_sched(d, t, d->split_k);
@@ -2072,11 +2104,20 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
     hipStream_t s = tsod_stream(stream);
     p.a_scale = 1.f; p.acc_scale = 1.f; p.range_flag = nullptr;
     if (d->precision == TSOD_PREC_FP16X2) {
-        TSOD_REQUIRE(sc.tile == TSOD_TILE_D128x128_K32, TSOD_ERR_UNSUPPORTED);
+        TSOD_REQUIRE(fp16x2_tile(sc.tile), TSOD_ERR_UNSUPPORTED);
         p.range_flag = d->range_flag;
         p.a_scale = ldexpf(1.f, d->a_scale_exp);
         p.acc_scale = ldexpf(1.f, -(d->a_scale_exp + d->w_scale_exp));
-        launch_dma_tile<128, 32, 2, 3, 1, 2>(p, sc.grid, s);
+        switch (sc.tile) {
+            case TSOD_TILE_64x64_S1: launch_tile<64, 64, 32, 32, 5, 1, 32, 2>(p, sc.grid, s); break;
+            case TSOD_TILE_128x64_W8_S1: launch_tile<128, 64, 32, 32, 3, 1, 32, 2>(p, sc.grid, s); break;
+            case TSOD_TILE_64x64_S1_K64: launch_tile<64, 64, 32, 32, 2, 1, 64, 2>(p, sc.grid, s); break;
+            case TSOD_TILE_128x64_S1: launch_tile<128, 64, 64, 32, 4, 1, 32, 2>(p, sc.grid, s); break;
+            case TSOD_TILE_64x128_S1: launch_tile<64, 128, 32, 64, 4, 1, 32, 2>(p, sc.grid, s); break;
+            case TSOD_TILE_128x128_S1: launch_tile<128, 128, 64, 64, 2, 1, 32, 2>(p, sc.grid, s); break;
+            case TSOD_TILE_D128x128_K32: launch_dma_tile<128, 32, 2, 3, 1, 2>(p, sc.grid, s); break;
+            default: launch_tile<64, 64, 32, 32, 2, 2, 32, 2>(p, sc.grid, s); break;      // TSOD_TILE_64x64 (two LDS stages)
+        }
         return tsod_launch_status();
     }
     if (d->precision == TSOD_PREC_BF16X3) {
