@@ -235,29 +235,31 @@ def test_detector_after_the_in_flight_refinement(dev, r50):
 
 
 @pytest.mark.parametrize("backbone,shape", [("resnet50", (1, 3, 800, 1333)), ("resnet50", (2, 3, 320, 448)), ("hardnet39", (2, 3, 320, 448))])
-def test_detector_with_every_dense_conv_in_bf16x3(dev, backbone, shape):
-    """SURVEY 8(f) rank 4, second half: the reduced-precision (bf16x3) conv path, gated by the SAME parity suite: the
-    whole trunk on three-piece bf16 MFMAs must give the oracle's RoIs / scores / classes to the bars of the f32 path."""
+@pytest.mark.parametrize("arith", ["bf16x3", "fp16x2"])
+def test_detector_with_every_dense_conv_in_bf16x3(dev, backbone, shape, arith):
+    """SURVEY 8(f) rank 4, second half: the split-operand conv paths (bf16x3: three bf16 pieces, six products; fp16x2: two fp16
+    pieces, three products), gated by the SAME parity suite: the whole trunk - HarDNet's concatenated-input layers included -
+    on them must give the oracle's RoIs / scores / classes to the bars of the f32 path."""
     from two_stage_object_detection_amd.testing import compare_detector_outputs, synthetic_detector
     model, sd = synthetic_detector(backbone, num_classes=20, seed=0)
     if backbone.startswith("hardnet"):
         oracle.calibrate_bn(sd, _img((2, 3, 256, 320), seed=99), oracle.hardnet_trunk, arch=int(backbone[-2:]), prefix="extractor.")
         model.load_state_dict(sd)
     model = model.to(dev).eval()
-    model.extractor.set_conv_precision("bf16x3")
+    model.extractor.set_conv_precision(arith)
     x = _img(shape)
     with torch.inference_mode():
         ref = oracle.detector_forward(sd, x, backbone=backbone)
         got = [o.cpu() for o in model(x.to(dev))]
         model.raise_if_error()
         plan = model.extractor._plan_for(x.to(dev))
-        assert all(p == 1 for _, _, _, p in plan.export_tiles())
+        assert all(p == (1 if arith == "bf16x3" else 2) for _, _, _, p in plan.export_tiles())
         feat_ref = oracle.detector.extractor_forward(sd, x, backbone)
         feat = model(x.to(dev), mode="extractor").cpu()
     scale = float(feat_ref.abs().max())
     assert float((feat - feat_ref).abs().max()) <= (2e-5 if backbone == "resnet50" else 5e-5) * scale + 1e-6     # the f32 path's feature bar
     rep = compare_detector_outputs(got, ref)
-    print("bf16x3", backbone, shape, rep)
+    print(arith, backbone, shape, rep)
     assert rep["ok"] and rep["rows_unmatched"] == 0 and rep["class_mismatch"] == 0, rep
     assert rep["rows_positional_mismatch"] <= 4, rep      # another arithmetic rounds differently: a near-tie may swap two rows
 

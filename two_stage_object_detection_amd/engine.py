@@ -240,6 +240,8 @@ class Plan:
         st.range_flag = self.range_flag
         st.fn = self.steps[-1][0]
         st.w_index, st.ws_index = (3, 8) if x2 is not None else (2, 7)
+        if precision == _ffi.PREC_FP16X2:                         # (weight image, scale exponents, range flag: choose() sets them)
+            st.choose(tile, split_k, precision)
         st.flops = 2 * N * OH * OW * getattr(pc, "cout_real", pc.cout) * pc.kh * pc.kw_logical * pc.cin_src   # algorithmic
         st.ws_bytes = 0
         self.conv_steps.append(st)
@@ -594,15 +596,16 @@ class PlanOwner:
     * ``weights_version`` counts invalidations: a graph captured by ``FasterRCNN.make_graphed`` refuses to replay once it
       is stale (it would run the old folded weights)."""
     max_plans = 8
-    conv_precision = "f32"       # "f32" | "bf16x3": default arithmetic of the dense convs of plans built from now on
+    conv_precision = "f32"       # "f32" | "bf16x3" | "fp16x2": default arithmetic of the dense convs of plans built from now on
     fuse_shortcut = True         # ResNet: a bottleneck's last 1x1 conv + its projection shortcut as one stacked-K GEMM
                                  # (set False + invalidate_packed() for the one-launch-per-conv plan, e.g. to pin a tile
                                  # table recorded from it)
 
     def set_conv_precision(self, precision: str):
-        """Arithmetic of the dense conv GEMMs: "f32" (v_mfma_f32_32x32x2_f32) or "bf16x3" (three exact bf16 pieces per
-        operand, six bf16 MFMAs per 16 k: f32-accurate, less matrix-pipe time).  Existing plans are dropped."""
-        if precision not in ("f32", "bf16x3"):
+        """Arithmetic of the dense conv GEMMs: "f32" (v_mfma_f32_32x32x2_f32), "bf16x3" (three exact bf16 pieces per
+        operand, six bf16 MFMAs per 16 k: f32-accurate, less matrix-pipe time) or "fp16x2" (two fp16 pieces of 16 x per operand,
+        three fp16 MFMAs per 16 k: f32-accurate while |x| < 4094 - raise_if_error() reports a violation).  Existing plans are dropped."""
+        if precision not in ("f32", "bf16x3", "fp16x2"):
             raise ValueError(precision)
         self.conv_precision = precision
         self.__dict__["_plans"] = OrderedDict()

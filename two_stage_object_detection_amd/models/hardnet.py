@@ -212,7 +212,7 @@ class HarDNetFeatureExtraction(PlanOwner, nn.Module):
             raise TsodError("depth_wise=False HarDNet (max-pool variant) has no HIP path; the reference only "
                             "uses depth_wise=True")
         plan = Plan(device, self._packed_cache)
-        plan.precision = 1 if self.conv_precision == "bf16x3" else 0
+        plan.precision = {"f32": 0, "bf16x3": 1, "fp16x2": 2}[self.conv_precision]
         L = lib()
         mods = list(self.base)
         x4 = plan.pool.alloc((N, H, W, 4))

@@ -167,7 +167,7 @@ class ResNet(PlanOwner, nn.Module):
         """Launch plan for a [N,3,H,W] input: NCHW->NHWC4, 7x7 stem as a 7x8x4 implicit GEMM with
         BN+PReLU, 3x3/s2 max pool, then the residual stages."""
         plan = Plan(device, self._packed_cache)
-        plan.precision = 1 if self.conv_precision == "bf16x3" else 0
+        plan.precision = {"f32": 0, "bf16x3": 1, "fp16x2": 2}[self.conv_precision]
         plan.fuse_shortcut = bool(self.fuse_shortcut)
         x4 = plan.pool.alloc((N, H, W, 4))
         plan.input_nhwc = x4
