@@ -89,7 +89,7 @@ enum { TSOD_TILE_AUTO = 0, TSOD_TILE_128x128 = 1, TSOD_TILE_128x64 = 2, TSOD_TIL
  * accumulation and epilogue are f32 either way.  Tiles available in BF16X3: 64x64, 64x64_S1, 128x64_W8_S1, 64x64_S1_K64,
  * 128x64_S1, 64x128_S1, 128x128_S1 (TSOD_ERR_UNSUPPORTED for the others). */
 enum { TSOD_PREC_F32 = 0, TSOD_PREC_BF16X3 = 1, TSOD_PREC_FP16X2 = 2 };
-/* FP16X2 (the register-staged BF16X3 tiles and TSOD_TILE_D128x128_K32): every f32 operand as TWO fp16 pieces of s * x
+/* FP16X2 (every BF16X3 tile but TSOD_TILE_D64x128 / _S2): every f32 operand as TWO fp16 pieces of s * x
  * (hi = rne(s x), lo = rne(s x - hi), s a power of two per tensor), THREE piece products per f32 product on
  * v_mfma_f32_32x32x16_f16, f32 accumulation: the f32 kernel's accuracy with half the MFMAs of BF16X3 - while |s x| stays
  * below fp16's 65504 (the CALLER picks desc.a_scale_exp for its activations' range; beyond it the piece products are inf /

@@ -173,7 +173,7 @@ def test_detector_with_the_fp16x2_arithmetic_among_the_candidates(dev, r50):
         forced = []
         for st, (name, tile, split, prec) in zip(plan.conv_steps, tuned):
             try:
-                st.choose(22, split if tile == 22 else -1, _ffi.PREC_FP16X2)
+                st.choose(22, split if tile == 22 else -1, _ffi.PREC_FP16X2)      # (the LDS-DMA tile where the layer can take it)
                 t_, s_ = ctypes.c_int32(0), ctypes.c_int32(0)
                 if _ffi.lib().tsod_conv2d_resolve(ctypes.byref(st.desc), ctypes.byref(t_), ctypes.byref(s_)) != 0:
                     raise _ffi.TsodError("unsupported")

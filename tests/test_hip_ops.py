@@ -593,10 +593,10 @@ def test_conv_fp16x2_matches_the_f64_convolution(ops, dev, N, Cin, Cout, H, W, k
     xn, wp = ops.nchw_to_nhwc(x.to(dev)), ops.pack_conv_weight(w.to(dev))
     rn = ops.nchw_to_nhwc(r.to(dev)) if res else None
     tol = 3e-6 * math.sqrt(k * k * Cin) + 1e-5
-    from two_stage_object_detection_amd._ffi import FP16X2_TILE_IDS
+    from two_stage_object_detection_amd._ffi import DMA_TILE_IDS, FP16X2_TILE_IDS
     e3 = (ops.nhwc_to_nchw(ops.conv2d_nhwc(xn, wp, pad=k // 2, tile=22, split_k=1, precision=1, residual=rn, act=1, slope=0.25)).cpu() - ref).abs().max().item()
     for tile in FP16X2_TILE_IDS:                                 # the LDS-DMA tile and the register-staged family
-        for split in (1, 3, -1) + ((-2,) if tile == 22 else ()):
+        for split in (1, 3, -1) + ((-2,) if tile in DMA_TILE_IDS else ()):
             out = ops.conv2d_nhwc(xn, wp, pad=k // 2, tile=tile, split_k=split, precision=2, residual=rn, act=1, slope=0.25, a_scale_exp=4)
             e = (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item()
             assert e <= tol and e <= 2 * e3 + 1e-7, (tile, split, e, e3, tol)
@@ -626,7 +626,7 @@ def test_conv_fp16x2_second_source_range_and_gates(ops, dev):
         assert (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item() <= tol, split
     out = ops.conv2d_nhwc(yn, w, segs=[(0, C1)], precision=2, x2=xn)                  # AUTO
     assert (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item() <= tol
-    for tile in (1, 2, 12, 17, 18, 21):                                            # f32-only tiles and the other LDS-DMA shapes
+    for tile in (1, 2, 12, 18, 20):                                                # f32-only tiles and the 64-row LDS-DMA shapes
         with pytest.raises(TsodError, match="unsupported|UNSUPPORTED"):
             ops.conv2d_nhwc(yn, w, segs=[(0, C1)], tile=tile, split_k=1, precision=2, x2=xn)
     for tile in (3, 14, 16):                                                       # the register-staged family takes the second source too

@@ -25,7 +25,7 @@ PREC_F32, PREC_BF16X3, PREC_FP16X2 = 0, 1, 2
 PREC_NAMES = {0: "f32", 1: "bf16x3", 2: "fp16x2"}
 DMA_TILE_IDS = (17, 18, 19, 20, 21, 22)                             # bf16x3 through LDS-DMA: one channel segment, Cin % 16 / % 32 == 0, bf16x3 ONLY
 BF16X3_TILE_IDS = (3, 8, 9, 10, 14, 15, 16) + DMA_TILE_IDS   # tiles that exist as bf16x3 variants (include/tsod.h)
-FP16X2_TILE_IDS = tuple(t for t in BF16X3_TILE_IDS if t not in DMA_TILE_IDS or t == 22)   # fp16x2: the register-staged bf16x3 tiles + d128x128k32
+FP16X2_TILE_IDS = tuple(t for t in BF16X3_TILE_IDS if t not in (18, 20))   # fp16x2: every bf16x3 tile but the 64-row LDS-DMA ones
 
 
 class TsodError(RuntimeError):

@@ -1764,7 +1764,10 @@ const TileInfo kTiles[TSOD_TILE_COUNT] = {
 
 // workgroups per CU: the f32 figure (VGPR / LDS bound), for bf16x3 additionally capped by its larger LDS footprint
 // tiles that exist in the fp16x2 arithmetic: the register-staged bf16x3 tiles and d128x128k32
-bool fp16x2_tile(int t) { return t == TSOD_TILE_D128x128_K32 || (kTiles[t].bf16x3 && !kTiles[t].dma); }
+bool fp16x2_tile(int t) {   // (the 64-row LDS-DMA tiles would need six DMA slots in a 12-MFMA phase: not built)
+    return t == TSOD_TILE_D128x128_K32 || t == TSOD_TILE_D128x128 || t == TSOD_TILE_D256x128 || t == TSOD_TILE_D128x256 ||
+           (kTiles[t].bf16x3 && !kTiles[t].dma);
+}
 
 int residency(int tile, int prec) {
     const TileInfo &t = kTiles[tile];
@@ -2116,6 +2119,9 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
             case TSOD_TILE_64x128_S1: launch_tile<64, 128, 32, 64, 4, 1, 32, 2>(p, sc.grid, s); break;
             case TSOD_TILE_128x128_S1: launch_tile<128, 128, 64, 64, 2, 1, 32, 2>(p, sc.grid, s); break;
             case TSOD_TILE_D128x128_K32: launch_dma_tile<128, 32, 2, 3, 1, 2>(p, sc.grid, s); break;
+            case TSOD_TILE_D128x128: launch_dma_tile<128, 16, 1, 4, 1, 2>(p, sc.grid, s); break;
+            case TSOD_TILE_D256x128: launch_dma_tile<256, 16, 1, 4, 1, 2>(p, sc.grid, s); break;
+            case TSOD_TILE_D128x256: launch_dma_tile<128, 16, 1, 4, 2, 2>(p, sc.grid, s); break;
             default: launch_tile<64, 64, 32, 32, 2, 2, 32, 2>(p, sc.grid, s); break;      // TSOD_TILE_64x64 (two LDS stages)
         }
         return tsod_launch_status();
