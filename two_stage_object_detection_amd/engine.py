@@ -100,7 +100,7 @@ FP16X2_A_SCALE_EXP = 4     # activations are split as 2^4 * x under the fp16x2 a
 
 
 def weights_fp16x2(pc):
-    """(fp16x2 image, w_scale_exp) of a packed layer's weights (experimental arithmetic, include/tsod.h TSOD_PREC_FP16X2),
+    """(fp16x2 image, w_scale_exp) of a packed layer's weights (include/tsod.h TSOD_PREC_FP16X2),
     made on first use and kept beside the f32 weights; the exponent brings max |w| just below 2^14."""
     hit = getattr(pc, "w2", None)
     if hit is None:

@@ -187,7 +187,7 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
     last C2 columns contracting channels [x2_off, x2_off + C2) of pixel (oh*stride2, ow*stride2) of ``x2`` (``kernel`` =
     (KH, KW, Cin) of the first source must be given through ``segs`` / a 1x1 filter: only 1x1 first sources here).
     ``w3``: the pre-split bf16x3 image of ``w_packed`` (pack_conv_weight_bf16x3) when the caller keeps one; used with
-    ``precision`` = bf16x3 instead of the wrapper's own cache.  ``precision`` = fp16x2 (experimental): activations are split as
+    ``precision`` = bf16x3 instead of the wrapper's own cache.  ``precision`` = fp16x2: activations are split as
     2^``a_scale_exp`` * x (|that| must stay below 65504), ``w2`` / ``w_scale_exp`` = the fp16x2 weight image and the exponent it
     was packed with (made on the spot from ``w_packed`` when not given); ``range_flag``: an int32 device word the launch sets to 1
     when an activation left that range."""

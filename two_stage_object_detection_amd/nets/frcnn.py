@@ -213,7 +213,7 @@ class FasterRCNN(nn.Module):
         return run, static_in, static_out
 
     def raise_if_error(self):
-        """Surface the deferred IndexError of the proposal padding and a range violation of the (opt-in) fp16x2 conv
+        """Surface the deferred IndexError of the proposal padding and a range violation of the fp16x2 conv
         arithmetic (one device sync each)."""
         self.rpn.raise_if_error()
         self.extractor.raise_if_error()
