@@ -485,6 +485,11 @@ def main(argv=None):
         model(x)                                                       # builds the plan
         torch.cuda.synchronize()
         plan = model.extractor._plan_for(x)
+        if args.precision in ("auto", "fp16x2"):
+            # the fp16x2 arithmetic's activation exponents from the ranges this model has on this input (16x headroom; every
+            # rank does it for itself - same model, same kind of input: same exponents; every later plan of the extractor,
+            # the in-flight slots' included, takes them from the owner)
+            plan.calibrate_fp16x2(x)
         default_tiles = plan.export_tiles()
         tiles = {"serial": default_tiles, "in_flight": default_tiles}
         splits = [int(v) for v in args.autotune_splits.split(",")] if args.autotune_splits else None

@@ -197,6 +197,42 @@ def test_detector_with_the_fp16x2_arithmetic_among_the_candidates(dev, r50):
         plan.import_tiles(before)
 
 
+def test_fp16x2_exponents_calibrated_to_the_models_range(dev, r50):
+    """Plan.calibrate_fp16x2 (what bench.py runs before it tunes): with every layer on fp16x2 at the default exponent (2^4: |x| <
+    4094) an image scaled by 300 drives the trunk's activations out of range and the forward must RAISE; after the calibration
+    on that input (exponents from the measured abs-max of every conv's input, 16x headroom) the same forward must give the
+    oracle's features to the f32 path's bar, raise nothing, and a new plan of the same extractor (another slot) must start
+    from the calibrated exponents."""
+    from two_stage_object_detection_amd import _ffi
+    model, sd, x, ref = r50
+    xb = (x * 300.0).to(dev)
+    model.extractor.set_conv_precision("fp16x2")
+    try:
+        with torch.inference_mode():
+            model.extractor.__dict__.get("_a_exps", {}).clear()
+            feat = model(xb, mode="extractor")
+            with pytest.raises(_ffi.TsodError, match="fp16x2"):
+                model.raise_if_error()
+            plan = model.extractor._plan_for(xb)
+            assert all(p == _ffi.PREC_FP16X2 for *_, p in plan.export_tiles())
+            seen = plan.calibrate_fp16x2(xb)
+            assert len(seen) == 49 and max(m for m, _ in seen.values()) > 4094 and min(e for _, e in seen.values()) < 4
+            assert all(int(st.desc.a_scale_exp) == seen[st.name][1] for st in plan.conv_steps)
+            feat = model(xb, mode="extractor").cpu()
+            model.raise_if_error()
+            feat_ref = oracle.detector.extractor_forward(sd, x * 300.0, "resnet50")
+            scale = float(feat_ref.abs().max())
+            assert float((feat - feat_ref).abs().max()) <= 2e-5 * scale + 1e-6
+            model(xb, slot=1, mode="extractor")
+            plan1 = model.extractor._plan_for(xb, 1)
+            assert all(int(st.desc.a_scale_exp) == seen[st.name][1] for st in plan1.conv_steps)
+            model.raise_if_error()
+    finally:
+        model.extractor.__dict__.get("_a_exps", {}).clear()
+        model.extractor.set_conv_precision("f32")
+        model.extractor.drop_plan(slot=1)
+
+
 def test_detector_after_the_in_flight_refinement(dev, r50):
     """bench.py's IN-FLIGHT table (round 3): after the first look (copies of one layer side by side) the three fastest
     candidates of every layer are tried again while all slots' streams run the whole conv sequence staggered around it

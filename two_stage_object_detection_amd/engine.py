@@ -155,7 +155,7 @@ def _merge_adjacent(segs):
 
 # --------------------------------------------------------------------------- plan
 class ConvStep:
-    __slots__ = ("desc", "args", "name", "flops", "ws_bytes", "pc", "fn", "w_index", "ws_index", "range_flag")
+    __slots__ = ("desc", "args", "name", "flops", "ws_bytes", "pc", "fn", "w_index", "ws_index", "range_flag", "x", "x2", "exps")
 
     def choose(self, tile: int, split_k: int, precision: int):
         """Pin (tile, K-slice schedule, arithmetic); the weight argument follows the arithmetic (f32 or pre-split bf16x3)."""
@@ -163,7 +163,7 @@ class ConvStep:
         d.tile, d.split_k, d.precision = int(tile), int(split_k), int(precision)
         if precision == _ffi.PREC_FP16X2:
             w2, e = weights_fp16x2(self.pc)
-            d.a_scale_exp, d.w_scale_exp = FP16X2_A_SCALE_EXP, int(e)
+            d.a_scale_exp, d.w_scale_exp = int(self.exps.get(self.name, FP16X2_A_SCALE_EXP)), int(e)
             d.range_flag = ptr(self.range_flag)                  # the plan's word: PlanOwner.raise_if_error reads it
             self.args[self.w_index] = ptr(w2)
         else:
@@ -185,6 +185,7 @@ class Plan:
         self.graph = None
         # fp16x2 layers OR 1 into this word when an activation left the arithmetic's range (include/tsod.h: range_flag)
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.a_exps: dict = {}               # layer name -> fp16x2 activation exponent (calibrate_fp16x2); the owner shares ONE dict among its plans
         self.flops = 0
 
     # -- building ---------------------------------------------------------------------------
@@ -238,6 +239,7 @@ class Plan:
         st = ConvStep()
         st.desc, st.args, st.name, st.pc = d, args, name, pc
         st.range_flag = self.range_flag
+        st.x, st.x2, st.exps = x, x2, self.a_exps                 # (the inputs: Plan.calibrate_fp16x2 measures their range)
         st.fn = self.steps[-1][0]
         st.w_index, st.ws_index = (3, 8) if x2 is not None else (2, 7)
         if precision == _ffi.PREC_FP16X2:                         # (weight image, scale exponents, range flag: choose() sets them)
@@ -266,6 +268,38 @@ class Plan:
             st.args[st.ws_index + 1] = self.workspace.numel()
         self.graph = None
         return self
+
+    # -- the fp16x2 arithmetic's activation scale -----------------------------------------------
+    def calibrate_fp16x2(self, x, headroom_bits: int = 4):
+        """Set every conv step's fp16x2 activation exponent from the range its input REALLY has on ``x`` (one forward, launch by
+        launch, abs-max of each conv's input(s) read right before it runs): 2^e * absmax <= 65504 / 2^headroom_bits, e clamped
+        to [-24, 8].  Without it every layer uses 2^4 (|x| < 4094); with it a model whose activations are larger (or much
+        smaller) than the synthetic detector's gets exponents that fit, with 16x headroom for other inputs - and the range guard
+        (include/tsod.h: range_flag) still watches every launch.  Returns {layer name: (absmax, exponent)}."""
+        import math
+        stage_input(self, x)
+        by_args = {id(st.args): st for st in self.conv_steps}
+        s = stream_ptr()
+        seen = {}
+        for fn, args in self.steps:
+            st = by_args.get(id(args))
+            if st is not None:
+                m = float(st.x.abs().max())
+                if st.x2 is not None:
+                    m = max(m, float(st.x2.abs().max()))
+                e = 8 if m == 0.0 or not math.isfinite(m) else max(-24, min(8, int(math.floor(math.log2(65504.0 / (m * (1 << headroom_bits)))))))
+                e = min(e, self.a_exps.get(st.name, e)) if st.name in seen else e      # (image groups of one layer: the smallest)
+                self.a_exps[st.name] = e
+                if int(st.desc.precision) == _ffi.PREC_FP16X2:
+                    st.desc.a_scale_exp = e
+                seen[st.name] = (m, e)
+            rc = fn(*args, s)
+            if rc != 0:
+                check(rc, getattr(fn, "__name__", "tsod call"))
+        torch.cuda.current_stream(self.device).synchronize()
+        self.range_flag.zero_()
+        self.graph = None                                        # (a captured graph has the old exponents baked in)
+        return seen
 
     # -- running ----------------------------------------------------------------------------
     def launch(self):
@@ -649,6 +683,13 @@ class PlanOwner:
         plan = plans.get(key)
         if plan is None:
             plan = plans[key] = build()
+            shared = self.__dict__.setdefault("_a_exps", {})      # fp16x2 activation exponents by layer name, for every plan of this owner
+            if isinstance(plan, Plan):
+                plan.a_exps = shared
+            for st in getattr(plan, "conv_steps", ()):
+                st.exps = shared
+                if int(st.desc.precision) == _ffi.PREC_FP16X2:    # (built in that arithmetic: choose() ran before the dict was shared)
+                    st.desc.a_scale_exp = int(shared.get(st.name, FP16X2_A_SCALE_EXP))
             while len(plans) > max(1, int(self.max_plans)):
                 plans.popitem(last=False)
         else:
