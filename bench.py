@@ -540,9 +540,15 @@ def main(argv=None):
             model.autotune_heads(x)                                    # the two GEMMs outside the backbone plan
             tiles["heads"] = model.head_choices()
         tuning_s = time.perf_counter() - t_tune
+        tiles["fp16x2_exps"] = dict(model.extractor.__dict__.get("_a_exps", {}))     # (kept in the tiles file too: they belong to the table)
         if world > 1:
             tiles = broadcast_json(tiles, rank, world)                 # rank 0's tables on every rank
             model.set_head_choices(tiles.get("heads"))
+        if tiles.get("fp16x2_exps"):
+            # rank 0's (or the file's) activation exponents on every rank and in every plan: the same arithmetic everywhere
+            model.extractor.__dict__.setdefault("_a_exps", {}).update({k: int(v) for k, v in tiles["fp16x2_exps"].items()})
+            plan.import_tiles(plan.export_tiles())                      # (re-pins the descriptors with those exponents)
+        if world > 1:
             all_tuning = [None] * world
             dist.all_gather_object(all_tuning, round(tuning_s, 2))
         else:

@@ -46,7 +46,7 @@ def _tile_tables():
                    glob.glob(os.path.join(ROOT, "profiles", "r*_b1_autotuned_tiles.json")))       # round 3 naming
     for f in files:
         d = json.load(open(f))
-        out += [(f, None)] if isinstance(d, list) else [(f, k) for k in sorted(d) if k != "heads"]   # heads: the two GEMMs outside the plan
+        out += [(f, None)] if isinstance(d, list) else [(f, k) for k in sorted(d) if k not in ("heads", "fp16x2_exps")]   # heads: the two GEMMs outside the plan; exps: not a table
     return out
 
 
