@@ -255,3 +255,26 @@ def test_head_choices_roundtrip_as_json():
     assert m2.rpn._gemm_choice == {(8, 25, 42): (3, 12, 1)} and m2.head._gemm_choice == {2400: (10, 2, 1)}
     m2.set_head_choices(None)                                   # nothing persisted: a no-op
     assert m2.head_choices() == blob
+
+
+def test_fp16x2_host_side_choices():
+    """The host side of the fp16x2 arithmetic: which tiles have it (every bf16x3 tile but the two 64-row LDS-DMA shapes), the
+    activation exponent picked for a measured range (16x headroom under fp16's 65504, clamped), and the weight exponent
+    (max |w| just below 2^14)."""
+    import torch
+    from two_stage_object_detection_amd import _ffi
+    from two_stage_object_detection_amd.engine import FP16X2_A_SCALE_EXP, fp16x2_activation_exp
+    from two_stage_object_detection_amd.hip_ops import fp16x2_weight_scale_exp
+    assert set(_ffi.FP16X2_TILE_IDS) == set(_ffi.BF16X3_TILE_IDS) - {18, 20} and 22 in _ffi.FP16X2_TILE_IDS
+    assert _ffi.PREC_NAMES[_ffi.PREC_FP16X2] == "fp16x2" and FP16X2_A_SCALE_EXP == 4
+    for m in (1e-3, 0.7, 100.0, 4093.0, 3e4, 1e9):
+        e = fp16x2_activation_exp(m)
+        assert -24 <= e <= 8
+        if -24 < e < 8:
+            assert (2.0 ** e) * m * 16 <= 65504.0 < (2.0 ** (e + 1)) * m * 16
+    assert fp16x2_activation_exp(100.0) == 5 and fp16x2_activation_exp(0.0) == 8 and fp16x2_activation_exp(float("inf")) == 8
+    assert fp16x2_activation_exp(1e12) == -24                                  # clamped: the guard reports what does not fit
+    for wmax in (1e-4, 0.02, 0.9, 37.0):
+        e = fp16x2_weight_scale_exp(torch.tensor([wmax, -wmax / 3, 0.0]))
+        assert 8192.0 < (2.0 ** e) * wmax <= 16384.0
+    assert fp16x2_weight_scale_exp(torch.zeros(4)) == 0

@@ -99,6 +99,15 @@ def weights_bf16x3(pc) -> torch.Tensor:
 FP16X2_A_SCALE_EXP = 4     # activations are split as 2^4 * x under the fp16x2 arithmetic: |x| < 4094 (65504 / 16) is its range
 
 
+def fp16x2_activation_exp(absmax: float, headroom_bits: int = 4) -> int:
+    """The fp16x2 activation exponent e for a tensor of that abs-max: 2^e * absmax <= 65504 / 2^headroom_bits, clamped to
+    [-24, 8] (8 for an all-zero or non-finite measurement: the guard decides at run time)."""
+    import math
+    if absmax == 0.0 or not math.isfinite(absmax):
+        return 8
+    return max(-24, min(8, int(math.floor(math.log2(65504.0 / (absmax * (1 << headroom_bits)))))))
+
+
 def weights_fp16x2(pc):
     """(fp16x2 image, w_scale_exp) of a packed layer's weights (include/tsod.h TSOD_PREC_FP16X2),
     made on first use and kept beside the f32 weights; the exponent brings max |w| just below 2^14."""
@@ -287,7 +296,7 @@ class Plan:
                 m = float(st.x.abs().max())
                 if st.x2 is not None:
                     m = max(m, float(st.x2.abs().max()))
-                e = 8 if m == 0.0 or not math.isfinite(m) else max(-24, min(8, int(math.floor(math.log2(65504.0 / (m * (1 << headroom_bits)))))))
+                e = fp16x2_activation_exp(m, headroom_bits)
                 e = min(e, self.a_exps.get(st.name, e)) if st.name in seen else e      # (image groups of one layer: the smallest)
                 self.a_exps[st.name] = e
                 if int(st.desc.precision) == _ffi.PREC_FP16X2:
