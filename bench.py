@@ -87,13 +87,10 @@ def parse(argv=None):
     ap.add_argument("--precision", default="auto", choices=("f32", "bf16x3", "auto", "auto-bf16x3", "fp16x2"), help="arithmetic of the "
                     "conv GEMMs: f32 = v_mfma_f32_32x32x2_f32; bf16x3 = three exact bf16 pieces per operand, six products on "
                     "v_mfma_f32_32x32x16_bf16; fp16x2 (for the layers whose tile has it, candidates like auto) = two fp16 pieces of "
-                    "16 x per operand, three products on v_mfma_f32_32x32x16_f16 - all three f32-accurate and gated by the same "
-                    "parity suite, fp16x2 while |x| < 4094 (beyond it the launch raises a range flag that "
-                    "FasterRCNN.raise_if_error() surfaces); auto (default) = the autotuner picks per layer among all three; "
+                    "2^e x per operand, three products on v_mfma_f32_32x32x16_f16, e from the abs-max the tensor's producers left "
+                    "in its range words (per forward, inside the launches: any finite input range) - all three f32-accurate and "
+                    "gated by the same parity suite; auto (default) = the autotuner picks per layer among all three; "
                     "auto-bf16x3 = among f32 and bf16x3 only (rounds 2-3)")
-    ap.add_argument("--autotune-concurrent", type=int, default=None, help="copies of a candidate in flight on separate streams while "
-                    "the in-flight tile table is tuned (default: --in-flight, i.e. 4: measured 697 -> 754 images/s on one box "
-                    "against tuning with 2 copies; 6 and 8 are no better)")
     ap.add_argument("--autotune-splits", default=None, help="comma list restricting the K-slice candidates of the autotuner")
     ap.add_argument("--autotune-in-sequence", type=int, default=None, help="serial tile table: the n fastest candidates of every layer "
                     "(timed in isolation) are timed again as launches of the whole conv sequence and the winner THERE is pinned "
@@ -165,7 +162,7 @@ def conv_event_times(plan, reps=5):
         e1.record()
         e1.synchronize()
         out.append(e0.elapsed_time(e1) / reps)
-    plan.range_flag.zero_()      # (these launches ran on whatever the pooled buffers held, not on a forward's activations)
+    plan.clear_range_flag()      # (these launches ran on whatever the pooled buffers held, not on a forward's activations)
     return out
 
 
@@ -187,23 +184,27 @@ def conv_sequence_time(plan, reps=10):
     e1.record()
     e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    plan.range_flag.zero_()      # (see conv_event_times)
+    plan.clear_range_flag()      # (see conv_event_times)
     return ms
 
 
 def cpu_baseline(sd, backbone, x_cpu, reps):
+    """(the oracle's outputs on x_cpu, the cpu_baseline object).  The outputs are what `parity` checks the timed plans against:
+    the line validates what it times."""
     import oracle
     # the GPU box exposes all host cores but grants this job a 16-core share (worker pools must be sized to it)
     torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("TSOD_CPU_THREADS", "16"))))
     with torch.inference_mode():
-        oracle.detector_forward(sd, x_cpu, backbone=backbone)           # warm-up
+        outs = oracle.detector_forward(sd, x_cpu, backbone=backbone)    # warm-up (and, with reps = 0, the reference of `parity` only)
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
-            oracle.detector_forward(sd, x_cpu, backbone=backbone)
+            outs = oracle.detector_forward(sd, x_cpu, backbone=backbone)
             ts.append(time.perf_counter() - t0)
+    if not ts:
+        return outs, None
     med = statistics.median(ts)
-    return {"value": x_cpu.shape[0] / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+    return outs, {"value": x_cpu.shape[0] / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{reps} timed forwards (median) of the same workload: batch {x_cpu.shape[0]} x 3x{x_cpu.shape[2]}x"
                       f"{x_cpu.shape[3]}, {backbone} detector, torch {torch.__version__} CPU f32 + oracle/box_ops.c",
             "seconds_per_forward": med}
@@ -256,9 +257,10 @@ def pmc_child(args, dev):
             plan.import_tiles(json.load(open(args.tiles_file))["serial"])
         torch.cuda.synchronize()
         L, s = lib(), stream_ptr()
-        for _ in range(2):                                  # pass 1 warms caches / code objects, pass 2 is the sample
-            for st in plan.conv_steps:
-                st.fn(*st.args, s)
+        model(x)                                            # a real forward: warms caches / code objects and leaves this input's
+        torch.cuda.synchronize()                            # activations and range words behind (the fp16x2 scales of the sample)
+        for st in plan.conv_steps:                          # the sample: one pass over the conv launches
+            st.fn(*st.args, s)
         torch.cuda.synchronize()
 
 
@@ -297,15 +299,31 @@ def pmc_traffic(args, tiles, n_launches):
                                                          or "conv_dma_kernel" in q["Kernel_Name"]
                                                          or "conv_reduce_kernel" in q["Kernel_Name"])]
             rows.sort()
-            if not rows or len(rows) % 2:
+            if len(rows) < 2 * n_launches:
                 return None, f"unexpected dispatch count {len(rows)} in the {counter} pass"
-            sums[counter] = sum(v for _, v in rows[len(rows) // 2:])          # the second of the two conv passes
+            sums[counter] = sum(v for _, v in rows[-n_launches:])             # the conv-only pass behind the warm-up forward
         total = (2.0 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"]) * 1024.0
         return total / n_launches, None
     except Exception as e:                                                     # noqa: BLE001 - never fail the bench on this leg
         return None, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def parity_of(gpu_outs, ref_outs):
+    """`parity` of the JSON line: the outputs the TIMED plans produced on this rank's images (the serial graph and one slot of
+    the in-flight server, tile tables and arithmetic exactly as timed) against the CPU oracle on the same images - boxes /
+    scores <= 1e-3, classes equal, every row paired one to one.  A line whose parity is not ok makes the run exit non-zero."""
+    from two_stage_object_detection_amd.testing import compare_detector_outputs
+    keys = ("rows", "rows_positional_mismatch", "rows_unmatched", "class_mismatch", "max_abs_roi", "max_abs_score", "max_abs_cls_loc", "ok")
+    legs = {}
+    for name, outs in gpu_outs.items():
+        rep = compare_detector_outputs(outs, ref_outs)
+        legs[name] = {k: (round(rep[k], 7) if isinstance(rep.get(k), float) else rep.get(k)) for k in keys}
+    worst = lambda k: max(v[k] for v in legs.values())      # noqa: E731
+    return {"rows_unmatched": worst("rows_unmatched"), "class_mismatch": worst("class_mismatch"), "max_abs_roi": worst("max_abs_roi"),
+            "max_abs_score": worst("max_abs_score"), "ok": all(v["ok"] for v in legs.values()), "atol": 1e-3, "matching": "one-to-one",
+            "against": "CPU oracle (oracle.detector_forward) on the timed input, rank 0's images", "legs": legs}
 
 
 class Timer:
@@ -484,18 +502,10 @@ def main(argv=None):
     with torch.inference_mode():
         model(x)                                                       # builds the plan
         torch.cuda.synchronize()
-        plan = model.extractor._plan_for(x)
-        if args.precision in ("auto", "fp16x2"):
-            # the fp16x2 arithmetic's activation exponents from the ranges this model has on this input (16x headroom; every
-            # rank does it for itself - same model, same kind of input: same exponents; every later plan of the extractor,
-            # the in-flight slots' included, takes them from the owner)
-            plan.calibrate_fp16x2(x)
+        plan = model.extractor._plan_for(x)                           # (the measurement legs below time its launches)
         default_tiles = plan.export_tiles()
         tiles = {"serial": default_tiles, "in_flight": default_tiles}
         splits = [int(v) for v in args.autotune_splits.split(",")] if args.autotune_splits else None
-        if splits is None and B >= 4:
-            splits = [1, -1, -2, 2, 4]    # large M: tiles already outnumber the chip's slots many times; deep K-slicing never wins
-                                           # there and only lengthens the tuning pass (8 ranks tune at once in the N > 1 runs)
         tiles_loaded = bool(args.tiles_file and os.path.exists(args.tiles_file))
         t_tune = time.perf_counter()
         if not tiles_loaded and not args.no_autotune:
@@ -506,48 +516,25 @@ def main(argv=None):
             while time.perf_counter() - t_w < 1.5:
                 conv_sequence_time(plan, reps=20)
         precs = {"f32": (0,), "bf16x3": (1,), "auto-bf16x3": (0, 1), "auto": (0, 1, 2), "fp16x2": (0, 1, 2)}[args.precision]
+        # The tuning goes through the public call (FasterRCNN.tune): what a user of the module surface gets is what is timed.
+        # fp16x2 needs no calibration pass: its activation scale follows every tensor per forward (range words).
         if tiles_loaded:
             tiles = json.load(open(args.tiles_file))
         elif not args.no_autotune and world > 1:
             # N > 1: ONE pass on rank 0 with the headline schedule's objective, shipped to every rank below (all ranks then
             # run the same kernels in the same summation order; start-up stays far inside the driver's limit)
             if rank == 0:
-                plan.autotune(verbose=args.verbose, splits=splits, concurrent=max(2, args.autotune_concurrent or n_fly) if n_fly > 1 else 1,
-                              precisions=precs)
-                tiles["serial"] = tiles["in_flight"] = plan.export_tiles()
+                tiles = model.tune(x, precisions=precs, in_flight=n_fly, schedules=("in_flight",) if n_fly > 1 else ("serial",),
+                                   splits=splits, in_sequence=0, in_flight_refine=0, verbose=args.verbose)
+                tiles["serial"] = tiles["in_flight"] = tiles.get("in_flight") or tiles["serial"]
         elif not args.no_autotune:
-            plan.autotune(verbose=args.verbose and rank == 0, splits=splits, concurrent=1, precisions=precs,
-                          in_sequence=args.autotune_in_sequence)
-            tiles["serial"] = plan.export_tiles()
-            if n_fly > 1:                                              # objective of an overlapped server: copies in flight
-                plan.autotune(verbose=False, splits=splits, concurrent=max(2, args.autotune_concurrent or n_fly), precisions=precs,
-                              keep_shortlist=args.autotune_in_flight_refine)
-                tiles["in_flight"] = plan.export_tiles()
-                if args.autotune_in_flight_refine > 0 and plan.last_shortlist:
-                    # second look on the real shape of the load: every slot's stream runs the whole conv sequence, staggered
-                    from two_stage_object_detection_amd.engine import refine_in_flight
-                    slot_plans = [plan]
-                    for sl in range(1, n_fly):
-                        model(x, slot=sl)
-                        slot_plans.append(model.extractor._plan_for(x, sl))
-                        slot_plans[-1].import_tiles(tiles["in_flight"])
-                    tiles["in_flight"] = refine_in_flight(slot_plans, plan.last_shortlist, verbose=args.verbose and rank == 0)
-            else:
-                tiles["in_flight"] = tiles["serial"]
-        if "heads" in tiles:
-            model.set_head_choices(tiles["heads"])                     # persisted choices: no tuning launches in this process
-        elif not args.no_autotune and (rank == 0 or world == 1):
-            model.autotune_heads(x)                                    # the two GEMMs outside the backbone plan
-            tiles["heads"] = model.head_choices()
+            tiles = model.tune(x, precisions=precs, in_flight=n_fly, splits=splits, in_sequence=args.autotune_in_sequence,
+                               in_flight_refine=args.autotune_in_flight_refine, verbose=args.verbose and rank == 0)
+            tiles.setdefault("in_flight", tiles["serial"])
         tuning_s = time.perf_counter() - t_tune
-        tiles["fp16x2_exps"] = dict(model.extractor.__dict__.get("_a_exps", {}))     # (kept in the tiles file too: they belong to the table)
         if world > 1:
             tiles = broadcast_json(tiles, rank, world)                 # rank 0's tables on every rank
-            model.set_head_choices(tiles.get("heads"))
-        if tiles.get("fp16x2_exps"):
-            # rank 0's (or the file's) activation exponents on every rank and in every plan: the same arithmetic everywhere
-            model.extractor.__dict__.setdefault("_a_exps", {}).update({k: int(v) for k, v in tiles["fp16x2_exps"].items()})
-            plan.import_tiles(plan.export_tiles())                      # (re-pins the descriptors with those exponents)
+        model.set_head_choices(tiles.get("heads"))                     # (persisted / broadcast choices: no tuning launches here)
         if world > 1:
             all_tuning = [None] * world
             dist.all_gather_object(all_tuning, round(tuning_s, 2))
@@ -579,8 +566,7 @@ def main(argv=None):
         f32_leg = None
         if world == 1 and not args.no_autotune and not args.no_graph and args.precision != "f32" and not (tiles_loaded and "f32" not in tiles):
             if "f32" not in tiles:
-                plan.autotune(verbose=False, splits=splits, concurrent=1, precisions=(0,))
-                tiles["f32"] = plan.export_tiles()
+                tiles["f32"] = model.tune(x, precisions=(0,), schedules=("serial",), splits=splits, in_sequence=0, heads=False)["serial"]
                 if args.tiles_file and rank == 0:
                     json.dump(tiles, open(args.tiles_file, "w"))
             plan.import_tiles(tiles["f32"])
@@ -595,8 +581,8 @@ def main(argv=None):
         bf_leg = None
         if world == 1 and not args.no_autotune and not args.no_graph and 2 in precs and not (tiles_loaded and "bf16x3" not in tiles):
             if "bf16x3" not in tiles:
-                plan.autotune(verbose=False, splits=splits, concurrent=1, precisions=(0, 1), in_sequence=args.autotune_in_sequence)
-                tiles["bf16x3"] = plan.export_tiles()
+                tiles["bf16x3"] = model.tune(x, precisions=(0, 1), schedules=("serial",), splits=splits,
+                                             in_sequence=args.autotune_in_sequence, heads=False)["serial"]
                 if args.tiles_file and rank == 0:
                     json.dump(tiles, open(args.tiles_file, "w"))
             plan.import_tiles(tiles["bf16x3"])
@@ -641,14 +627,23 @@ def main(argv=None):
             serial_server = InFlightDetector(model, x, depth=1, tiles=tiles["serial"])
         serial = timer.measure(make_step(serial_server, 1), args.steps, args.warmup, args.repeats)
         serial_server.drain()
+        timed_outs = {}                                                   # what the timed plans computed on x (checked in `parity`)
+        if rank == 0 and not args.no_graph:
+            timed_outs["serial"] = [o.cpu() for o in serial_server.result(serial_server.submit())[:4]]
         # ---- schedule 2: --in-flight steps overlapped on as many streams (the default headline)
         if n_fly > 1:
             server = InFlightDetector(model, x, depth=n_fly, tiles=tiles["in_flight"])
             fly = timer.measure(make_step(server, n_fly), args.steps, args.warmup, args.repeats)
             server.drain()
+            if rank == 0:                                                  # the slot the next request would use
+                timed_outs[f"in_flight_slot{server._next % n_fly}"] = [o.cpu() for o in server.result(server.submit())[:4]]
+                server.drain()
         else:
             server, fly = serial_server, serial
         model.raise_if_error()
+        if rank == 0 and args.no_graph:
+            timed_outs["serial_eager"] = [o.cpu() for o in model(x)]
+            model.raise_if_error()
 
         check = None
         if args.check and world > 1:
@@ -668,6 +663,7 @@ def main(argv=None):
                 dist.destroy_process_group()
                 sys.exit(3)
 
+    exit_code = 0
     if rank == 0:
         head = fly
         conv_total_ms = conv_seq_ms                                       # one pass in forward order (agrees with the kernel trace)
@@ -685,8 +681,8 @@ def main(argv=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if n_bf + n_h2 == 0 else "f32 storage/accumulate; conv products as bf16x3 (3 exact bf16 pieces per operand, "
                                               f"6 bf16 MFMAs per product) in {n_bf} of {len(precs)} conv layers, "
-                                              + (f"as fp16x2 (2 fp16 pieces of 16 x per operand, 3 fp16 MFMAs per product: f32-accurate while "
-                                                 f"|x| < 4094, which every launch checks - a violation raises) in {n_h2}, " if n_h2 else "")
+                                              + (f"as fp16x2 (2 fp16 pieces of 2^e x per operand, 3 fp16 MFMAs per product; e follows the tensor's abs-max per "
+                                                 f"forward: range words) in {n_h2}, " if n_h2 else "")
                                               + "f32 MFMA in the rest",
             "data": "synthetic",
             "config": {"workload": f"Full Faster R-CNN {args.backbone} inference forward, batch={B} per GPU, "
@@ -743,12 +739,22 @@ def main(argv=None):
             line["roofline_bf16x3"] = bf_leg
         if check is not None:
             line["check"] = check
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, args.backbone, x_cpu, args.cpu_reps)
+        parity = None
+        if not args.no_cpu_baseline:
+            # N = 1: the timed oracle forwards double as the reference of `parity`; N > 1: one untimed oracle forward of rank 0's shard
+            ref_outs, cpu = cpu_baseline(sd, args.backbone, x_cpu, args.cpu_reps if n_gpus == 1 else 0)
+            if n_gpus == 1:
+                line["cpu_baseline"] = cpu
+            parity = parity_of(timed_outs, ref_outs)
+        line["parity"] = parity
         print(json.dumps(line), flush=True)
+        if parity is not None and not parity["ok"]:
+            exit_code = 4
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

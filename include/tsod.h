@@ -32,11 +32,13 @@
 extern "C" {
 #endif
 
-#define TSOD_VERSION 231 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
+#define TSOD_VERSION 240 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
                             ticket area in the workspace), pitched tsod_detections_f32, new entry points;
                             0.2.1: conv tiles fed by LDS-DMA (bf16x3), balanced K schedule (split_k = -2);
                             0.2.2: tsod_allgather_f32 + communicator helpers (RCCL bound at run time);
-                            0.3.0: tsod_bbox2loc_f32; a dual-source conv's c2 must be whole K-steps of the tile */
+                            0.3.0: tsod_bbox2loc_f32; a dual-source conv's c2 must be whole K-steps of the tile;
+                            0.4.0: range words (conv descriptor grew: amax_in / amax_in2 / amax_out; tsod_absmax_f32 and the
+                            *_amax_f32 entry points): the fp16x2 activation scale follows the tensor per forward */
 
 typedef void *tsod_stream_t; /* hipStream_t */
 
@@ -142,7 +144,28 @@ typedef struct tsod_conv2d_desc {
      * (and what genuinely non-finite input produces).  The outputs of such a launch are not to be used; clear the word and
      * run the layer with TSOD_PREC_BF16X3 or a smaller a_scale_exp. */
     int32_t *range_flag;
+    /* Range words (optional, NULL = off; see "Range words" below).  amax_out: this launch adds the abs-max of the values it
+     * stores to the words.  amax_in (and amax_in2 for the second source): TSOD_PREC_FP16X2 only - the launch takes its
+     * activation exponent from the words (2^e * absmax < 2^15) instead of a_scale_exp: the scale follows the tensor per forward,
+     * so no input range can leave the arithmetic (range_flag then only reports non-finite input). */
+    const uint32_t *amax_in, *amax_in2;
+    uint32_t *amax_out;
 } tsod_conv2d_desc;
+
+/* Range words: the abs-max of an activation tensor, kept by its PRODUCERS for its consumers.  One tensor = TSOD_AMAX_WORDS
+ * uint32 words TSOD_AMAX_STRIDE bytes apart (TSOD_AMAX_BYTES in all, 64-byte aligned), each the bit pattern of a non-negative
+ * f32; the abs-max is the largest word.  The caller zero-fills the words once per forward (stream-ordered, e.g.
+ * hipMemsetAsync) before the first producer runs; every producing launch adds one atomic max per workgroup (spread over the
+ * words: a single word would serialise ~11.5 ns per workgroup); several producers may share the words of one buffer (HarDNet's
+ * block buffers), a tensor that is a max-pool or RoI-pool of another may share its producer's.  Everything is stream-ordered and
+ * capturable; nothing is read by the host. */
+#define TSOD_AMAX_WORDS 64
+#define TSOD_AMAX_STRIDE 64
+#define TSOD_AMAX_BYTES (TSOD_AMAX_WORDS * TSOD_AMAX_STRIDE)
+/* zero the words of `n_tensors` consecutive tensors (a memset node under stream capture): once per forward */
+int tsod_amax_reset(uint32_t *words, int32_t n_tensors, tsod_stream_t stream);
+/* abs-max of n floats into the words (for tensors no libtsod kernel produced: an image handed over in NHWC(4) layout) */
+int tsod_absmax_f32(const float *x, int64_t n, uint32_t *amax_out, tsod_stream_t stream);
 
 /* Packed weight layout Wp: [Cout][KH][KW][Cin] f32 (k = (kh*KW + kw)*Cin + ci, ci running over
  * the concatenated segments).  tsod_pack_conv_weight_f32 converts torch's [Cout][Cin_src][KH][KW]:
@@ -197,6 +220,11 @@ int tsod_dwconv3x3_f32(const float *in, int32_t N, int32_t H, int32_t W, int32_t
                        const float *w, const float *scale, const float *shift, int32_t stride, int32_t relu,
                        float *out, int32_t out_pitch, int32_t out_off, tsod_stream_t stream);
 
+/* ... the same, adding the abs-max of what it stores to the range words `amax_out` (NULL: exactly tsod_dwconv3x3_f32) */
+int tsod_dwconv3x3_amax_f32(const float *in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_pitch, int32_t in_off,
+                            const float *w, const float *scale, const float *shift, int32_t stride, int32_t relu,
+                            float *out, int32_t out_pitch, int32_t out_off, uint32_t *amax_out, tsod_stream_t stream);
+
 /* Grouped 3x3 conv, pad 1, stride 1|2, C -> C channels in `groups` groups + per-channel scale/shift (folded BN) + activation:
  * the conv2 of the ResNeXt bottleneck (models/resnet.py:46-47 with groups = 32, width_per_group = 4; factory :167-172).
  * w is [C][3][3][C/groups]; C/groups must be a multiple of 4.  act / slope as in tsod_conv2d_desc. */
@@ -204,15 +232,25 @@ int tsod_gconv3x3_f32(const float *in, int32_t N, int32_t H, int32_t W, int32_t 
                       const float *w, const float *scale, const float *shift, int32_t stride, int32_t act, float slope,
                       float *out, int32_t out_pitch, tsod_stream_t stream);
 
+int tsod_gconv3x3_amax_f32(const float *in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_pitch, int32_t groups,
+                           const float *w, const float *scale, const float *shift, int32_t stride, int32_t act, float slope,
+                           float *out, int32_t out_pitch, uint32_t *amax_out, tsod_stream_t stream);
+
 /* nn.Conv2d(2G, G, 1, groups=G) + bias: models/hardnet.py:196.
  * out[.., g] = w[g][0]*in[.., 2g] + w[g][1]*in[.., 2g+1] + bias[g].  w is [G][2]. */
 int tsod_gconv1x1_pair_f32(const float *in, int64_t pixels, int32_t G, int32_t in_pitch, const float *w,
                            const float *bias, float *out, int32_t out_pitch, tsod_stream_t stream);
 
+int tsod_gconv1x1_pair_amax_f32(const float *in, int64_t pixels, int32_t G, int32_t in_pitch, const float *w,
+                                const float *bias, float *out, int32_t out_pitch, uint32_t *amax_out, tsod_stream_t stream);
+
 /* Layout changes at the module boundary (the reference's tensors are NCHW).
  * nchw_to_nhwc writes channels [0,C) of each pixel and zero-fills [C, C_pad) (C_pad <= out_pitch). */
 int tsod_nchw_to_nhwc_f32(const float *in, int32_t N, int32_t C, int32_t H, int32_t W,
                           float *out, int32_t out_pitch, int32_t C_pad, tsod_stream_t stream);
+/* ... adding the image batch's abs-max to the range words `amax_out` (NULL: exactly tsod_nchw_to_nhwc_f32) */
+int tsod_nchw_to_nhwc_amax_f32(const float *in, int32_t N, int32_t C, int32_t H, int32_t W,
+                               float *out, int32_t out_pitch, int32_t C_pad, uint32_t *amax_out, tsod_stream_t stream);
 int tsod_nhwc_to_nchw_f32(const float *in, int32_t N, int32_t C, int32_t H, int32_t W, int32_t in_pitch,
                           int32_t in_off, float *out, tsod_stream_t stream);
 

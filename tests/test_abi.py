@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_symbols():
         assert hasattr(raw, name), name
     lib = _ffi.lib()
-    assert lib.tsod_version() == 231
+    assert lib.tsod_version() == 240
     assert lib.tsod_status_str(0) == b"ok"
     assert b"workspace" in lib.tsod_status_str(-4)
 
@@ -37,18 +37,21 @@ def test_conv_desc_layout_matches_header(tmp_path):
     """The ctypes mirror of tsod_conv2d_desc against the C compiler's own layout of include/tsod.h (size and the offsets
     of the first, a middle and the last field)."""
     import subprocess
-    # 5 + 16 + 16 + 3 + 5 + 2 + 1 + 1(float) + 5 (.. precision) + 6 (second source) + 2 (fp16x2 scale exponents) int32-sized fields + one pointer
-    assert ctypes.sizeof(_ffi.ConvDesc) == 4 * (5 + 16 + 16 + 3 + 5 + 2 + 1 + 1 + 5 + 6 + 2) + 8
+    # 5 + 16 + 16 + 3 + 5 + 2 + 1 + 1(float) + 5 (.. precision) + 6 (second source) + 2 (fp16x2 scale exponents) int32-sized fields
+    # + four pointers (range_flag, amax_in, amax_in2, amax_out)
+    assert ctypes.sizeof(_ffi.ConvDesc) == 4 * (5 + 16 + 16 + 3 + 5 + 2 + 1 + 1 + 5 + 6 + 2) + 4 * 8
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tsod.h"\nint main(void) { printf("%zu %zu %zu %zu %zu\\n", '
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tsod.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %d %d\\n", '
                    'sizeof(tsod_conv2d_desc), offsetof(tsod_conv2d_desc, Cout), offsetof(tsod_conv2d_desc, slope), '
-                   'offsetof(tsod_conv2d_desc, split_k), offsetof(tsod_conv2d_desc, range_flag)); return 0; }\n')
+                   'offsetof(tsod_conv2d_desc, split_k), offsetof(tsod_conv2d_desc, range_flag), offsetof(tsod_conv2d_desc, amax_in2), '
+                   'offsetof(tsod_conv2d_desc, amax_out), TSOD_AMAX_WORDS, TSOD_AMAX_STRIDE); return 0; }\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
-    size, o_cout, o_slope, o_split, o_prec = (int(v) for v in subprocess.check_output([str(exe)]).split())
+    size, o_cout, o_slope, o_split, o_prec, o_in2, o_out, words, stride = (int(v) for v in subprocess.check_output([str(exe)]).split())
     D = _ffi.ConvDesc
-    assert (size, o_cout, o_slope, o_split, o_prec) == (ctypes.sizeof(D), D.Cout.offset, D.slope.offset, D.split_k.offset,
-                                                        D.range_flag.offset)
+    assert (size, o_cout, o_slope, o_split, o_prec, o_in2, o_out) == (ctypes.sizeof(D), D.Cout.offset, D.slope.offset, D.split_k.offset,
+                                                                      D.range_flag.offset, D.amax_in2.offset, D.amax_out.offset)
+    assert (words, stride) == (_ffi.AMAX_WORDS, _ffi.AMAX_STRIDE)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -797,3 +797,110 @@ def test_dma_conv_tiles_at_full_layer_sizes(ops, dev, shape):
             assert torch.equal(y4, y * 4.0), (tile, split, "linearity in 4 must be exact")
     z = ops.conv2d_nhwc(torch.zeros_like(x), w, pad=k // 2, tile=DMA_TILE_IDS[0], split_k=-2, precision=1)
     assert torch.count_nonzero(z).item() == 0
+
+
+def test_range_words_producers_hold_the_abs_max(ops, dev):
+    """Range words (include/tsod.h): every producing kernel adds the abs-max of what it STORES to its tensor's 64 words - both conv
+    kernel families (whole tiles, K-slices' last arrivers, the balanced schedule, vector and scalar epilogues), the layout
+    kernels, the depthwise / grouped kernels and tsod_absmax_f32.  Bit-exact: the largest word IS the output's abs-max."""
+    import ctypes
+    from two_stage_object_detection_amd import _ffi
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(2, 64, 23, 29, generator=g)
+    x[1, 5, 7, 11] = -37.5
+    words = ops.new_amax_words(dev, 8)
+    xn = ops.nchw_to_nhwc(x.to(dev))
+    L, s = _ffi.lib(), _ffi.stream_ptr
+    # layout (small-C and tiled) + absmax
+    x3 = torch.randn(2, 3, 17, 19, generator=g) * 3
+    o4 = torch.empty(2, 17, 19, 4, device=dev)
+    _ffi.check(L.tsod_nchw_to_nhwc_amax_f32(_ffi.ptr(x3.to(dev)), 2, 3, 17, 19, _ffi.ptr(o4), 4, 4, words[0].data_ptr(), s()))
+    assert ops.amax_value(words[0]) == float(x3.abs().max())
+    o64 = torch.empty(2, 23, 29, 64, device=dev)
+    _ffi.check(L.tsod_nchw_to_nhwc_amax_f32(_ffi.ptr(x.to(dev)), 2, 64, 23, 29, _ffi.ptr(o64), 64, 64, words[1].data_ptr(), s()))
+    assert ops.amax_value(words[1]) == 37.5 and torch.equal(o64, xn)
+    ops.absmax(xn, words[2])
+    assert ops.amax_value(words[2]) == 37.5
+    odd = torch.randn(1001, generator=g).to(dev)                      # (no float4 path)
+    ops.absmax(odd, words[3])
+    assert ops.amax_value(words[3]) == float(odd.abs().max())
+    # conv: every arithmetic / kernel family / K schedule; the words accumulate (max) over launches, so one slot per launch
+    w = torch.randn(96, 64, 3, 3, generator=g) / 24.0
+    wp = ops.pack_conv_weight(w.to(dev))
+    res = ops.nchw_to_nhwc(torch.randn(2, 96, 23, 29, generator=g).to(dev))
+    for prec, tile, split in ((0, 3, 1), (0, 1, 3), (0, 8, -1), (1, 14, 1), (1, 22, 3), (1, 19, -2), (2, 22, 1), (2, 17, -2), (2, 8, 2), (2, 15, -1)):
+        slot = ops.new_amax_words(dev, 1)
+        out = ops.conv2d_nhwc(xn, wp, pad=1, residual=res, act=1, slope=0.25, tile=tile, split_k=split, precision=prec, amax_out=slot)
+        assert ops.amax_value(slot) == float(out.abs().max()), (prec, tile, split)
+    # scalar epilogue (Cout not a multiple of 4) and a channel slice of a wider output
+    w54 = torch.randn(54, 64, 1, 1, generator=g) / 8.0
+    slot = ops.new_amax_words(dev, 1)
+    out = ops.conv2d_nhwc(xn, ops.pack_conv_weight(w54.to(dev)), amax_out=slot)
+    assert ops.amax_value(slot) == float(out.abs().max())
+    # depthwise, pair conv, grouped conv
+    wd = torch.randn(3, 3, 64, generator=g).to(dev)
+    od = torch.zeros(2, 23, 29, 64, device=dev)
+    _ffi.check(L.tsod_dwconv3x3_amax_f32(_ffi.ptr(xn), 2, 23, 29, 64, 64, 0, _ffi.ptr(wd), None, None, 1, 0, _ffi.ptr(od), 64, 0, words[4].data_ptr(), s()))
+    assert ops.amax_value(words[4]) == float(od.abs().max()) > 0
+    wpair = torch.randn(32, 2, generator=g).to(dev)
+    op = torch.zeros(2 * 23 * 29, 32, device=dev)
+    _ffi.check(L.tsod_gconv1x1_pair_amax_f32(_ffi.ptr(xn), 2 * 23 * 29, 32, 64, _ffi.ptr(wpair), None, _ffi.ptr(op), 32, words[5].data_ptr(), s()))
+    assert ops.amax_value(words[5]) == float(op.abs().max()) > 0
+    wg = torch.randn(64, 3, 3, 8, generator=g).to(dev)
+    og = torch.zeros(2, 23, 29, 64, device=dev)
+    _ffi.check(L.tsod_gconv3x3_amax_f32(_ffi.ptr(xn), 2, 23, 29, 64, 64, 8, _ffi.ptr(wg), None, None, 1, 1, ctypes.c_float(0.25), _ffi.ptr(og), 64,
+                                        words[6].data_ptr(), s()))
+    assert ops.amax_value(words[6]) == float(og.abs().max()) > 0
+    # reset
+    _ffi.check(L.tsod_amax_reset(words.data_ptr(), 8, s()))
+    assert int(words.abs().max()) == 0
+    # a misaligned word pointer is refused
+    with pytest.raises(_ffi.TsodError):
+        ops.conv2d_nhwc(xn, wp, pad=1, amax_out=words[0].data_ptr() + 4)
+
+
+@pytest.mark.parametrize("scale", [1.0, 300.0, 1e-3, 3e4, 2e-7])
+def test_conv_fp16x2_scale_follows_the_tensor(ops, dev, scale):
+    """fp16x2 with range words: the activation exponent comes from the abs-max the input's producer left - per launch, in the
+    kernel - so the SAME f32 accuracy holds whatever the tensor's range (here 2e-7 ... 3e4 times a PReLU-shaped normal tensor:
+    far outside the static 2^4 exponent's |x| < 4094 on one side and deep in fp16's subnormals on the other), in both kernel
+    families, under K-slices and the balanced schedule, and for the second source (the larger of the two tensors decides).  The
+    range flag stays down; it fires for non-finite input only."""
+    g = torch.Generator().manual_seed(77)
+    N, Cin, Cout, H, W, k = 1, 128, 128, 27, 31, 3
+    x = torch.randn(N, Cin, H, W, generator=g)
+    x = torch.maximum(x, 0.25 * x) * scale
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(k * k * Cin)
+    ref = F.conv2d(x.double(), w.double(), padding=1).float()
+    xn, wp = ops.nchw_to_nhwc(x.to(dev)), ops.pack_conv_weight(w.to(dev))
+    words = ops.absmax(xn, ops.new_amax_words(dev, 1))
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    tol = (3e-6 * math.sqrt(k * k * Cin) + 1e-5) * scale
+    from two_stage_object_detection_amd._ffi import DMA_TILE_IDS, FP16X2_TILE_IDS
+    for tile in FP16X2_TILE_IDS:
+        for split in (1, 3) + ((-2,) if tile in DMA_TILE_IDS else ()):
+            out = ops.conv2d_nhwc(xn, wp, pad=1, tile=tile, split_k=split, precision=2, amax_in=words, range_flag=flag)
+            e = (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item()
+            assert e <= tol, (tile, split, e, tol)
+    assert int(flag.item()) == 0
+    # second source: the stacked-K GEMM with x2 1000 times larger than x - the exponent must follow the larger tensor
+    C2 = 64
+    x2 = torch.randn(N, C2, H, W, generator=g) * scale * 1000.0
+    wd = torch.randn(Cout, C2, 1, 1, generator=g) / math.sqrt(C2)
+    w1 = torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    ref2 = (F.conv2d(x.double(), w1.double()) + F.conv2d(x2.double(), wd.double())).float()
+    x2n = ops.nchw_to_nhwc(x2.to(dev))
+    words2 = ops.absmax(x2n, ops.new_amax_words(dev, 1))
+    wst = torch.cat([w1.flatten(1), wd.flatten(1)], dim=1).contiguous().to(dev)
+    for tile in (22, 14):
+        out = ops.conv2d_nhwc(xn, wst, segs=[(0, Cin)], tile=tile, split_k=1, precision=2, x2=x2n, amax_in=words, amax_in2=words2, range_flag=flag)
+        assert (ops.nhwc_to_nchw(out).cpu() - ref2).abs().max().item() <= 3e-6 * math.sqrt(Cin + C2) * scale * 1000.0 + 1e-5 * scale, tile
+    assert int(flag.item()) == 0
+    # non-finite input: the words cannot help, the flag must say so
+    xbad = xn.clone()
+    xbad[0, 3, 4, 5] = float("inf")
+    wbad = ops.absmax(xbad, ops.new_amax_words(dev, 1))
+    for tile in (22, 8):
+        flag.zero_()
+        ops.conv2d_nhwc(xbad, wp, pad=1, tile=tile, split_k=1, precision=2, amax_in=wbad, range_flag=flag)
+        assert int(flag.item()) == 1, tile

@@ -278,3 +278,48 @@ def test_fp16x2_host_side_choices():
         e = fp16x2_weight_scale_exp(torch.tensor([wmax, -wmax / 3, 0.0]))
         assert 8192.0 < (2.0 ** e) * wmax <= 16384.0
     assert fp16x2_weight_scale_exp(torch.zeros(4)) == 0
+
+
+def test_compare_detector_outputs_is_one_to_one():
+    """The matcher behind every end-to-end parity claim pairs rows ONE TO ONE: a reference RoI that the GPU side replaced by a
+    duplicate of another row is a missing row (it used to pass: both copies claimed the same reference row), a pure
+    permutation is not, and nothing unmatched is tolerated by ``ok``."""
+    from two_stage_object_detection_amd.testing import compare_detector_outputs
+    g = torch.Generator().manual_seed(3)
+    R, n = 12, 5
+    rois = torch.rand(1, R, 4, generator=g) * 500
+    scores = torch.randn(1, R, n, generator=g)
+    locs = torch.randn(1, R, 4 * n, generator=g)
+    idx = torch.zeros(1, dtype=torch.int32)
+    ref = (locs, scores, rois, idx)
+    rep = compare_detector_outputs(ref, ref)
+    assert rep["ok"] and rep["rows_unmatched"] == 0 and rep["rows_positional_mismatch"] == 0 and rep["matching"] == "one-to-one"
+    # two rows trade places: every row still has its own partner
+    perm = torch.arange(R)
+    perm[3], perm[4] = 4, 3
+    swapped = (locs[:, perm], scores[:, perm], rois[:, perm], idx)
+    rep = compare_detector_outputs(swapped, ref)
+    assert rep["ok"] and rep["rows_unmatched"] == 0 and rep["rows_positional_mismatch"] == 2
+    # row 7 replaced by a copy of row 2: reference row 7 has no partner any more
+    dup = [t.clone() for t in (locs, scores, rois)]
+    for t in dup:
+        t[0, 7] = t[0, 2]
+    rep = compare_detector_outputs((dup[0], dup[1], dup[2], idx), ref)
+    assert not rep["ok"] and rep["rows_unmatched"] == 1 and rep["rows_positional_mismatch"] == 1
+    # genuine duplicates on BOTH sides (the reference's padding rule repeats rows) pair up among themselves
+    both = [t.clone() for t in (locs, scores, rois)]
+    for t in both:
+        t[0, 9:] = t[0, 0:3]
+    both_sw = [t[:, [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 9, 11]] for t in both]
+    rep = compare_detector_outputs((both_sw[0], both_sw[1], both_sw[2], idx), (both[0], both[1], both[2], idx))
+    assert rep["ok"] and rep["rows_unmatched"] == 0
+    # a class flip on a matched row is a failure of its own
+    flip = scores.clone()
+    flip[0, 1] = flip[0, 1].flip(0)
+    rep = compare_detector_outputs((locs, flip, rois, idx), ref)
+    assert not rep["ok"] and rep["rows_unmatched"] == 0
+    # a NaN box matches nothing
+    bad = rois.clone()
+    bad[0, 5, 0] = float("nan")
+    rep = compare_detector_outputs((locs, scores, bad, idx), ref)
+    assert not rep["ok"] and rep["rows_unmatched"] == 1

@@ -15,6 +15,8 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSOD_LIB") or os.path.join(_PKG_DIR, "libtsod.so")   # TSOD_LIB: alternate build (experiments)
 
 TSOD_MAX_SEGMENTS = 16
+AMAX_WORDS, AMAX_STRIDE = 64, 64                 # range words of one tensor (include/tsod.h): 64 uint32, 64 bytes apart
+AMAX_BYTES = AMAX_WORDS * AMAX_STRIDE
 ACT_NONE, ACT_PRELU, ACT_RELU6, ACT_RELU = 0, 1, 2, 3
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4
 TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "64x128", 5: "128x128w8", 6: "128x64w8", 7: "256x128w8",
@@ -44,6 +46,7 @@ class ConvDesc(Structure):
         ("res_pitch", c_int32), ("res_off", c_int32), ("tile", c_int32), ("split_k", c_int32), ("precision", c_int32),
         ("c2", c_int32), ("in2_pitch", c_int32), ("in2_off", c_int32), ("stride2", c_int32), ("H2", c_int32), ("W2", c_int32),
         ("a_scale_exp", c_int32), ("w_scale_exp", c_int32), ("range_flag", c_void_p),
+        ("amax_in", c_void_p), ("amax_in2", c_void_p), ("amax_out", c_void_p),
     ]
 
 
@@ -69,6 +72,14 @@ _SIGNATURES = {
     "tsod_maxpool3x3s2_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "tsod_dwconv3x3_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                    c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
+    "tsod_dwconv3x3_amax_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                        c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "tsod_gconv3x3_amax_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                       c_int32, c_int32, c_float, c_void_p, c_int32, c_void_p, c_void_p]),
+    "tsod_gconv1x1_pair_amax_f32": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "tsod_nchw_to_nhwc_amax_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "tsod_absmax_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "tsod_amax_reset": (c_int, [c_void_p, c_int32, c_void_p]),
     "tsod_gconv3x3_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                   c_int32, c_int32, c_float, c_void_p, c_int32, c_void_p]),
     "tsod_gconv1x1_pair_f32": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
@@ -137,8 +148,8 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.tsod_version() != 231:
-            raise TsodError(f"{LIB_PATH} is version {l.tsod_version()}, this package binds version 231 of include/tsod.h: rebuild it "
+        if l.tsod_version() != 240:
+            raise TsodError(f"{LIB_PATH} is version {l.tsod_version()}, this package binds version 240 of include/tsod.h: rebuild it "
                             "(`make -C two_stage_object_detection_amd/csrc`)")
         _lib = l
     return _lib

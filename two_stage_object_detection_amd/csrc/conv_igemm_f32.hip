@@ -85,6 +85,11 @@ struct ConvParams {
                                   //    contiguous channel run, so (kh, kw, channel base) are wave-uniform and live on the scalar unit
     float neg_slope, act_hi;      // activation as min(max(v,0) + neg_slope*min(v,0), act_hi)
     float inv_cin, inv_kw;        // reciprocals for the branch-free k -> (kh, kw, ci) split
+    // range words (include/tsod.h): amax_out - the abs-max of what this launch stores is added to them (one atomic max per
+    // workgroup); amax_in / amax_in2 (fp16x2 only) - the activation scale comes from them instead of a_scale / acc_scale
+    const unsigned *amax_in, *amax_in2;
+    unsigned *amax_out;
+    int w_scale_exp;              // fp16x2: exponent the weight image was packed with (acc_scale = 2^-(activation exponent + this))
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -214,6 +219,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
     constexpr int TM = WM / 32, TN = WN / 32;
     const int lane = tid & 63, wave = tid >> 6;
     const int z = sm.z;
+    float amax = 0.f;             // largest |value| this thread stores (range words: tsod_amax_commit at every exit that stored)
     // ---- epilogue.  acc[i][j][e]: column = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (m).
     // All global accesses go through buffer descriptors: rows / columns outside the problem get the
     // out-of-range offset, so there is no per-element branch (loads return 0, stores are dropped), and the
@@ -376,11 +382,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
                 float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
                 if (p.vec_epilogue) {                                      // Cout % 4 == 0: all four channels exist
                     const float4 sc = sc4, sh = sh4;
+                    const float o0 = apply_act(vv[0] * sc.x + sh.x + rs4[u].x, p.neg_slope, p.act_hi);
+                    const float o1 = apply_act(vv[1] * sc.y + sh.y + rs4[u].y, p.neg_slope, p.act_hi);
+                    const float o2 = apply_act(vv[2] * sc.z + sh.z + rs4[u].z, p.neg_slope, p.act_hi);
+                    const float o3 = apply_act(vv[3] * sc.w + sh.w + rs4[u].w, p.neg_slope, p.act_hi);
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o0), fabsf(o1))), fmaxf(fabsf(o2), fabsf(o3)));
                     u32x4 o;
-                    o.x = __float_as_uint(apply_act(vv[0] * sc.x + sh.x + rs4[u].x, p.neg_slope, p.act_hi));
-                    o.y = __float_as_uint(apply_act(vv[1] * sc.y + sh.y + rs4[u].y, p.neg_slope, p.act_hi));
-                    o.z = __float_as_uint(apply_act(vv[2] * sc.z + sh.z + rs4[u].z, p.neg_slope, p.act_hi));
-                    o.w = __float_as_uint(apply_act(vv[3] * sc.w + sh.w + rs4[u].w, p.neg_slope, p.act_hi));
+                    o.x = __float_as_uint(o0); o.y = __float_as_uint(o1); o.z = __float_as_uint(o2); o.w = __float_as_uint(o3);
                     __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u, 0, 0);
                 } else {
 #pragma unroll
@@ -388,7 +396,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
                         if (n + c >= p.Cout) continue;
                         float o = vv[c] * (p.scale ? p.scale[n + c] : 1.f) + (p.shift ? p.shift[n + c] : 0.f);
                         if (p.res) o += p.res[(long)m * p.res_pitch + p.res_off + n + c];
-                        p.out[(long)m * p.out_pitch + p.out_off + n + c] = apply_act(o, p.neg_slope, p.act_hi);
+                        o = apply_act(o, p.neg_slope, p.act_hi);
+                        amax = fmaxf(amax, fabsf(o));
+                        p.out[(long)m * p.out_pitch + p.out_off + n + c] = o;
                     }
                 }
             }
@@ -396,6 +406,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 #ifdef TSOD_CLOCK_DIAG
         if (eo) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); eo[4] = __builtin_amdgcn_s_memtime(); }
 #endif
+        if (p.amax_out != nullptr) tsod_amax_commit(p.amax_out, amax, smem, tid, THREADS);   // (the last arriver stored the tile)
         return;
     }
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, (short)0, (int)p.out_bytes, 0x00020000);
@@ -452,17 +463,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int m = mb + 8 * t;
-                    const unsigned off = (m < p.M && n_ok) ? ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u : kOOB;
+                    const bool ok = m < p.M && n_ok;
+                    const unsigned off = ok ? ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u : kOOB;
+                    const float o0 = apply_act(v[t].x * sc.x + sh.x + rs[t].x, p.neg_slope, p.act_hi);
+                    const float o1 = apply_act(v[t].y * sc.y + sh.y + rs[t].y, p.neg_slope, p.act_hi);
+                    const float o2 = apply_act(v[t].z * sc.z + sh.z + rs[t].z, p.neg_slope, p.act_hi);
+                    const float o3 = apply_act(v[t].w * sc.w + sh.w + rs[t].w, p.neg_slope, p.act_hi);
+                    const float m4 = fmaxf(fmaxf(fabsf(o0), fabsf(o1)), fmaxf(fabsf(o2), fabsf(o3)));
+                    amax = fmaxf(amax, ok ? m4 : 0.f);               // (rows / columns outside the problem are not stored)
                     u32x4 o;
-                    o.x = __float_as_uint(apply_act(v[t].x * sc.x + sh.x + rs[t].x, p.neg_slope, p.act_hi));
-                    o.y = __float_as_uint(apply_act(v[t].y * sc.y + sh.y + rs[t].y, p.neg_slope, p.act_hi));
-                    o.z = __float_as_uint(apply_act(v[t].z * sc.z + sh.z + rs[t].z, p.neg_slope, p.act_hi));
-                    o.w = __float_as_uint(apply_act(v[t].w * sc.w + sh.w + rs[t].w, p.neg_slope, p.act_hi));
+                    o.x = __float_as_uint(o0); o.y = __float_as_uint(o1); o.z = __float_as_uint(o2); o.w = __float_as_uint(o3);
                     __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next block overwrites it
             }
         }
+        if (p.amax_out != nullptr) tsod_amax_commit(p.amax_out, amax, smem, tid, THREADS);
         return;
     }
 #pragma unroll
@@ -489,12 +505,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = mb + (e & 3) + 8 * (e >> 2);
-                const unsigned off = (m < p.M && n_ok) ? ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u : kOOB;
+                const bool ok = m < p.M && n_ok;
+                const unsigned off = ok ? ((unsigned)m * (unsigned)p.out_pitch + (unsigned)(p.out_off + n)) * 4u : kOOB;
                 const float v = apply_act(acc[i][j][e] * sc + sh + r[e], p.neg_slope, p.act_hi);
+                amax = fmaxf(amax, ok ? fabsf(v) : 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, off, 0, 0);
             }
         }
     }
+    if (p.amax_out != nullptr) tsod_amax_commit(p.amax_out, amax, smem, tid, THREADS);
+}
+
+// fp16x2 with range words: the activation exponent from the abs-max the producers left (one word per lane), the accumulators'
+// way back from it and the weight image's exponent.  Every wave computes the same (wave-uniform) pair for itself.
+__device__ __forceinline__ void fp16x2_scales_from_bits(unsigned bits, int w_scale_exp, float &a_scale, float &acc_scale) {
+    const int e = tsod_fp16x2_exp_from_bits(bits);
+    a_scale = __uint_as_float((unsigned)(127 + e) << 23);
+    acc_scale = __uint_as_float((unsigned)(127 - e - w_scale_exp) << 23);
 }
 
 // BM x BN workgroup tile, WM x WN per-wave tile: (BM/WM) x (BN/WN) waves of 64 lanes.
@@ -550,6 +577,17 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    float a_scale = p.a_scale, acc_scale = p.acc_scale;            // fp16x2: static exponents, or (range words) the tensor's own
+    if constexpr (PREC == 2) {
+        if (p.amax_in != nullptr) {                                  // (wave-uniform; the load flies under the first K-step's loads)
+            unsigned bits = p.amax_in[lane * TSOD_AMAX_STRIDE_WORDS];
+            if (p.amax_in2 != nullptr) { const unsigned b2 = p.amax_in2[lane * TSOD_AMAX_STRIDE_WORDS]; bits = b2 > bits ? b2 : bits; }
+            fp16x2_scales_from_bits(tsod_amax_reduce_bits(bits), p.w_scale_exp, a_scale, acc_scale);
+        }
+        // (both are wave-uniform: scalar registers, as the kernel arguments they replace were)
+        a_scale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(a_scale)));
+        acc_scale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(acc_scale)));
+    }
 
     // ---- workgroup -> work.  Whole-tile workgroups come first and are remapped so that each XCD (private
     // L2; blocks b, b+8, ... share one) walks a contiguous run of tiles sharing activation rows.  K-slice
@@ -695,8 +733,8 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
         } else {
             unsigned h[2], m[2], l[2];
             if constexpr (PREC == 2) {
-                split2_pair(v.x, v.y, p.a_scale, h[0], l[0]);
-                split2_pair(v.z, v.w, p.a_scale, h[1], l[1]);
+                split2_pair(v.x, v.y, a_scale, h[0], l[0]);
+                split2_pair(v.z, v.w, a_scale, h[1], l[1]);
                 m[0] = m[1] = 0;
             } else {
                 split3_pair(v.x, v.y, h[0], m[0], l[0]);
@@ -903,7 +941,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    acc[i][j][e] *= p.acc_scale;
+                    acc[i][j][e] *= acc_scale;
                     bad |= !(fabsf(acc[i][j][e]) <= 3.4028234664e38f);
                 }
         if (p.range_flag != nullptr && __any(bad) && lane == 0) atomicOr(p.range_flag, 1);
@@ -956,6 +994,10 @@ __device__ __forceinline__ void dma16(unsigned voff, v4i32 rsrc, unsigned soff, 
     else
         asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen" TSOD_DMA_POLICY_A " lds"
                      :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst), "s"(slot_off) : "memory", "scc");
+}
+// one wave-instruction: 64 lanes x 4 bytes from per-lane source offsets to LDS [lds_dst, lds_dst + 256) (the range words)
+__device__ __forceinline__ void dma4(unsigned voff, v4i32 rsrc, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, 0 offen lds" :: "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
 }
 // s_waitcnt lgkmcnt(N) that the uses of `x` (an LDS read's destination) cannot be scheduled above
 template <int N, typename T> __device__ __forceinline__ void wait_lgkm_for(T &x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N) : "memory"); }
@@ -1126,7 +1168,10 @@ conv_dma_kernel(const ConvParams p) {
     constexpr int TAB_N = kDmaTabEntries, TAB_BYTES = TAB_N * 16, TAB_OFF = S * STAGE + (B_PAD ? 1024 : 0);
     constexpr int LB_WGS = (2 * S * dma_stage_bytes(BM, BK, 128 * WAVES_N, NPL) <= 160 * 1024) ? 2 : 1;
     constexpr bool TABLE = LB_WGS * (TAB_OFF + TAB_BYTES) <= 160 * 1024;
-    __shared__ __align__(16) unsigned char lds[TAB_OFF + (TABLE ? TAB_BYTES : 0)];
+    // fp16x2: 2 x 256 bytes behind the table for the range words of the two sources (the bf16x3 d128x128 ring fills the LDS of two
+    // workgroups per CU exactly and has no use for them)
+    constexpr int AMAX_OFF = TAB_OFF + (TABLE ? TAB_BYTES : 0), AMAX_LDS = NPL == 2 ? 512 : 0;
+    __shared__ __align__(16) unsigned char lds[AMAX_OFF + AMAX_LDS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WAVES_M, wk = (wave / WAVES_M) % WAVES_K, wn = wave / (WAVES_M * WAVES_K);
@@ -1145,6 +1190,23 @@ conv_dma_kernel(const ConvParams p) {
     if (balanced) {
         g = (long)blockIdx.x * p.sk_q;
         g_end = min(g + (long)p.sk_q, (long)p.tiles_m * p.tiles_n * p.ksteps);
+    }
+    // fp16x2 activation scale: the descriptor's static exponent, or - range words - the exponent the tensor's abs-max calls for.
+    // The words come in by LDS-DMA like everything else (wave 0, BEFORE the first ring fill: the oldest vector-memory operation,
+    // so every counted wait of the prologue covers it) and are read behind the prologue's barrier; nothing waits for them alone.
+    float a_scale = p.a_scale;
+    bool amax_pending = false;
+    if constexpr (NPL == 2) {
+        if (p.amax_in != nullptr) {
+            amax_pending = true;
+            if (wave == 0) {
+                const unsigned l0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)lds + AMAX_OFF;
+                dma4((unsigned)lane * TSOD_AMAX_STRIDE, dma_rsrc(p.amax_in, TSOD_AMAX_BYTES), (unsigned)__builtin_amdgcn_readfirstlane((int)l0));
+                // (no second source: the same words again, so that the reader below has no branch)
+                dma4((unsigned)lane * TSOD_AMAX_STRIDE, dma_rsrc(p.amax_in2 ? p.amax_in2 : p.amax_in, TSOD_AMAX_BYTES),
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)(l0 + 256)));
+            }
+        }
     }
   for (; g < g_end;) {
     int tile_id, kt_begin, kt_end;
@@ -1170,8 +1232,8 @@ conv_dma_kernel(const ConvParams p) {
     const int nk = kt_end - kt_begin;
     __syncthreads();                                             // (a previous segment's epilogue is done with the LDS)
 
-    const v4i32 rs_in = dma_rsrc(p.in, p.in_bytes), rs_w = dma_rsrc(p.w, p.w_bytes);
-    const v4i32 rs_in2 = dma_rsrc(p.in2 ? p.in2 : p.in, p.in2 ? p.in2_bytes : 0u);
+    v4i32 rs_in = dma_rsrc(p.in, p.in_bytes), rs_w = dma_rsrc(p.w, p.w_bytes);
+    v4i32 rs_in2 = dma_rsrc(p.in2 ? p.in2 : p.in, p.in2 ? p.in2_bytes : 0u);
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)lds;
     const int kgroups = p.K / 8;
 
@@ -1324,6 +1386,7 @@ conv_dma_kernel(const ConvParams p) {
         }
     };
 
+    float a_scale_s = p.a_scale;                                  // fp16x2: the activation scale as a scalar operand of the loop's statements
     f32x16 acc[1][TN];
 #ifdef TSOD_DIAG_MFMA16
     Acc16 pacc[TN];                                               // the probe's accumulators (acc is zeroed behind the loop instead)
@@ -1402,7 +1465,7 @@ conv_dma_kernel(const ConvParams p) {
             wait_lgkm<4>();
         }
 #define TSOD_SPLIT2(N0, X0, X1, G)                                                                        \
-        gap2_a(TSOD_MF2(N0), X0, X1, p.a_scale, xs0, xs1, hh[G], t0, t1);                                  \
+        gap2_a(TSOD_MF2(N0), X0, X1, a_scale_s, xs0, xs1, hh[G], t0, t1);                                  \
         gap2_b<B_PLANE>(TSOD_MF2(N0 + 1), xs0, xs1, t0, t1, r0, r1, ll[G], nxt.b[G][1], b_addr[G] + soff); \
         TSOD_DMA2(1 + G);
         TSOD_SPLIT2(4, raw0.x, raw0.y, 0)
@@ -1553,6 +1616,21 @@ conv_dma_kernel(const ConvParams p) {
 #ifdef TSOD_CLOCK_DIAG
         if (dg_on) { const long long c = __builtin_amdgcn_s_memtime(); dg_pro += c - dg_c; dg_c = c; }
 #endif
+        if constexpr (NPL == 2) {
+            if (amax_pending) {                                  // (wave-uniform; once per workgroup: the scale is the launch's)
+                const unsigned *wds = reinterpret_cast<const unsigned *>(lds + AMAX_OFF);
+                const unsigned b1 = wds[lane], b2 = wds[64 + lane];
+                float acc_unused;
+                fp16x2_scales_from_bits(tsod_amax_reduce_bits(b2 > b1 ? b2 : b1), 0, a_scale, acc_unused);
+                amax_pending = false;
+            }
+        }
+        a_scale_s = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(a_scale)));
+        // every scalar the loop reads must BE in its register here: a kernel-argument load of the compiler's own that is still
+        // pending at the loop head costs a conservative lgkmcnt(0) inside the phase, in front of the table entry's first use -
+        // which then waits for the four fragment reads issued behind the entry as well (seen in the balanced instantiation once
+        // the range words had lengthened the prologue: the descriptors were re-loaded late)
+        asm volatile("" : "+s"(rs_w), "+s"(rs_in), "+s"(rs_in2), "+s"(a_scale_s));
         Frags X, Y;
         {
             const float4 raw0 = *reinterpret_cast<const float4 *>(lds + (a_addr[0] - lds0));
@@ -1563,10 +1641,10 @@ conv_dma_kernel(const ConvParams p) {
                 for (int pl = 0; pl < NPL; ++pl) X.b[j][pl] = *reinterpret_cast<const bf16x8 *>(lds + (b_addr[j] - lds0) + pl * B_PLANE);
             unsigned hh[4], mm[4], ll[4];
             if constexpr (NPL == 2) {
-                split2_pair(raw0.x, raw0.y, p.a_scale, hh[0], ll[0]);
-                split2_pair(raw0.z, raw0.w, p.a_scale, hh[1], ll[1]);
-                split2_pair(raw1.x, raw1.y, p.a_scale, hh[2], ll[2]);
-                split2_pair(raw1.z, raw1.w, p.a_scale, hh[3], ll[3]);
+                split2_pair(raw0.x, raw0.y, a_scale_s, hh[0], ll[0]);
+                split2_pair(raw0.z, raw0.w, a_scale_s, hh[1], ll[1]);
+                split2_pair(raw1.x, raw1.y, a_scale_s, hh[2], ll[2]);
+                split2_pair(raw1.z, raw1.w, a_scale_s, hh[3], ll[3]);
                 mm[0] = mm[1] = mm[2] = mm[3] = 0;
             } else {
                 split3_pair(raw0.x, raw0.y, hh[0], mm[0], ll[0]);
@@ -1604,11 +1682,18 @@ conv_dma_kernel(const ConvParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // asm-issued MFMA results -> ordinary reads
     }
 #undef TSOD_DMA
+    // The epilogue reads its parameters from the kernel-argument segment (the struct is the only argument) instead of from
+    // `p`: values that only the epilogue needs then do not occupy scalar registers across the K loop (under the balanced
+    // schedule's segment loop they pushed the loop's own scalars out into v_readlane / v_writelane).
+    const ConvParams &pe = *(const ConvParams *)__builtin_amdgcn_kernarg_segment_ptr();
     if constexpr (NPL == 2) {                                    // back from (a_scale x) . (weight scale w) to x . w (a power of two: exact)
+        if (amax_pending) wait_vm<0>();                           // (a workgroup without K-steps never waited for its range-word DMAs)
+        // 1 / (a_scale * 2^w_scale_exp), from the scale that was really used (static or from the range words)
+        const float acc_scale = __uint_as_float((unsigned)(254 - (int)(__float_as_uint(a_scale_s) >> 23) - pe.w_scale_exp) << 23);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[0][j][e] *= p.acc_scale;
+            for (int e = 0; e < 16; ++e) acc[0][j][e] *= acc_scale;
         // the range guard: an activation beyond 65504 / a_scale splits into +-inf pieces whose products make EVERY accumulator
         // it feeds inf or NaN (a zero weight gives 0 * inf = NaN too), so a finite tile proves its inputs were in range; a
         // non-finite one (also from genuinely non-finite input) raises the caller's flag - the epilogue's branch-free
@@ -1633,10 +1718,6 @@ conv_dma_kernel(const ConvParams p) {
     if (dg_on) { const long long c = __builtin_amdgcn_s_memtime(); dg_loop += c - dg_c; dg_c = c; }
 #endif
     float *smem = reinterpret_cast<float *>(lds);
-    // The epilogue reads its parameters from the kernel-argument segment (the struct is the only argument) instead of from
-    // `p`: values that only the epilogue needs then do not occupy scalar registers across the K loop (under the balanced
-    // schedule's segment loop they pushed the loop's own scalars out into v_readlane / v_writelane).
-    const ConvParams &pe = *(const ConvParams *)__builtin_amdgcn_kernarg_segment_ptr();
     if constexpr (WAVES_K == 2) {
         // the two K halves of a 32 x 128 stripe sit in waves (wm, 0) and (wm, 1): each keeps the 64 columns [64 wk, 64 wk + 64),
         // hands the other 64 over through LDS ([wave][block][e][lane], lane-contiguous) and adds what its partner handed over
@@ -2106,9 +2187,16 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
     TSOD_REQUIRE(sc.ws_bytes < 0xFFFFFFF0ull, TSOD_ERR_UNSUPPORTED);
     hipStream_t s = tsod_stream(stream);
     p.a_scale = 1.f; p.acc_scale = 1.f; p.range_flag = nullptr;
+    p.amax_in = nullptr; p.amax_in2 = nullptr; p.w_scale_exp = 0;
+    p.amax_out = d->amax_out;
+    TSOD_REQUIRE((reinterpret_cast<uintptr_t>(d->amax_out) & 63u) == 0 && (reinterpret_cast<uintptr_t>(d->amax_in) & 63u) == 0 &&
+                     (reinterpret_cast<uintptr_t>(d->amax_in2) & 63u) == 0, TSOD_ERR_ALIGNMENT);
     if (d->precision == TSOD_PREC_FP16X2) {
         TSOD_REQUIRE(fp16x2_tile(sc.tile), TSOD_ERR_UNSUPPORTED);
         p.range_flag = d->range_flag;
+        p.amax_in = d->amax_in;                                   // (NULL: the static a_scale_exp)
+        p.amax_in2 = (d->amax_in != nullptr && p.c2 > 0) ? d->amax_in2 : nullptr;
+        p.w_scale_exp = d->w_scale_exp;
         p.a_scale = ldexpf(1.f, d->a_scale_exp);
         p.acc_scale = ldexpf(1.f, -(d->a_scale_exp + d->w_scale_exp));
         switch (sc.tile) {

@@ -60,17 +60,15 @@ maxpool3x3s2_kernel(const float *__restrict__ in, int N, int H, int W, int C4, i
 // four-column form, and one thread's index arithmetic is shared by R*OUTS outputs.  An output's taps are accumulated in
 // ascending (dh, dw) order whatever R and OUTS are; taps in the zero padding add 0*k like the reference's padded conv.
 template <int STRIDE, int OUTS, int R>
-__global__ void __launch_bounds__(256)
-dwconv3x3_kernel(const float *__restrict__ in, int N, int H, int W, int C4, int in_pitch, int in_off,
+__device__ __forceinline__ float
+dwconv3x3_thread(long t, const float *__restrict__ in, int N, int H, int W, int C4, int in_pitch, int in_off,
                  const float *__restrict__ w, const float *__restrict__ scale, const float *__restrict__ shift,
                  int relu, int OH, int OW, float *__restrict__ out, int out_pitch, int out_off) {
     constexpr int COLS = (OUTS - 1) * STRIDE + 3;
     constexpr int NROWS = (R - 1) * STRIDE + 3;
     const int OWG = (OW + OUTS - 1) / OUTS;
     const int ORB = (OH + R - 1) / R;
-    const long total = (long)N * ORB * OWG * C4;
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (XCD bands of the block order measured no faster here)
-    if (t >= total) return;
+    float amax = 0.f;                                            // largest |value| this thread stores (range words)
     const int c4 = (int)(t % C4);
     long u = t / C4;
     const int og = (int)(u % OWG);
@@ -136,6 +134,7 @@ dwconv3x3_kernel(const float *__restrict__ in, int N, int H, int W, int C4, int 
                     const float4 a = acc[r][o];
                     float4 v = make_float4(a.x * s.x + b.x, a.y * s.y + b.y, a.z * s.z + b.z, a.w * s.w + b.w);
                     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                     *reinterpret_cast<float4 *>(orow + (long)o * out_pitch) = v;
                 }
             }
@@ -145,12 +144,28 @@ dwconv3x3_kernel(const float *__restrict__ in, int N, int H, int W, int C4, int 
             for (int c = 0; c < COLS; ++c) cur[c] = nxt[c];
         }
     }
+    return amax;
+}
+
+template <int STRIDE, int OUTS, int R>
+__global__ void __launch_bounds__(256)
+dwconv3x3_kernel(const float *__restrict__ in, int N, int H, int W, int C4, int in_pitch, int in_off,
+                 const float *__restrict__ w, const float *__restrict__ scale, const float *__restrict__ shift,
+                 int relu, int OH, int OW, float *__restrict__ out, int out_pitch, int out_off, unsigned *amax_out) {
+    const long total = (long)N * ((OH + R - 1) / R) * ((OW + OUTS - 1) / OUTS) * C4;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (XCD bands of the block order measured no faster here)
+    const float amax = t < total ? dwconv3x3_thread<STRIDE, OUTS, R>(t, in, N, H, W, C4, in_pitch, in_off, w, scale, shift, relu, OH, OW,
+                                                                      out, out_pitch, out_off) : 0.f;
+    __shared__ float s_amax[4];
+    if (amax_out != nullptr) tsod_amax_commit(amax_out, amax, s_amax, threadIdx.x, 256);
 }
 
 __global__ void __launch_bounds__(256)
 gconv1x1_pair_kernel(const float *__restrict__ in, long pixels, int G, int in_pitch, const float *__restrict__ w,
-                     const float *__restrict__ bias, float *__restrict__ out, int out_pitch) {
+                     const float *__restrict__ bias, float *__restrict__ out, int out_pitch, unsigned *amax_out) {
     const long total = pixels * G;
+    float amax = 0.f;
+    __shared__ float s_amax[4];
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int g = (int)(t % G);
         const long px = t / G;
@@ -158,32 +173,57 @@ gconv1x1_pair_kernel(const float *__restrict__ in, long pixels, int G, int in_pi
         const float2 k = *reinterpret_cast<const float2 *>(w + 2 * g);
         float o = v.x * k.x + v.y * k.y;
         if (bias) o += bias[g];
+        amax = fmaxf(amax, fabsf(o));
         out[px * out_pitch + g] = o;
     }
+    if (amax_out != nullptr) tsod_amax_commit(amax_out, amax, s_amax, threadIdx.x, 256);
 }
 
 // C <= 4 images (the RGB input): one thread per pixel, planes read coalesced along w.
 __global__ void __launch_bounds__(256)
 nchw_to_nhwc_small_kernel(const float *__restrict__ in, int N, int C, long HW, float *__restrict__ out, int out_pitch,
-                          int C_pad) {
+                          int C_pad, unsigned *amax_out) {
     const long total = (long)N * HW;
+    float amax = 0.f;
+    __shared__ float s_amax[4];
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const long n = t / HW, px = t - n * HW;
         float v[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = c < C ? in[(n * C + c) * HW + px] : 0.f;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         float *o = out + t * out_pitch;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (c < C_pad) o[c] = v[c];
     }
+    if (amax_out != nullptr) tsod_amax_commit(amax_out, amax, s_amax, threadIdx.x, 256);
+}
+
+// abs-max of n floats into the range words (n % 4 == 0 and 16-byte alignment give the float4 path)
+__global__ void __launch_bounds__(256)
+absmax_kernel(const float *__restrict__ x, long n, unsigned *amax_out) {
+    float amax = 0.f;
+    __shared__ float s_amax[4];
+    const bool vec = (n & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+    if (vec) {
+        for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n / 4; t += (long)gridDim.x * blockDim.x) {
+            const float4 v = reinterpret_cast<const float4 *>(x)[t];
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    } else {
+        for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) amax = fmaxf(amax, fabsf(x[t]));
+    }
+    tsod_amax_commit(amax_out, amax, s_amax, threadIdx.x, 256);
 }
 
 // generic 32x32 tiled transposes through LDS (pitch 33: conflict-free column reads)
 __global__ void __launch_bounds__(256)
 nchw_to_nhwc_tile_kernel(const float *__restrict__ in, int C, long HW, float *__restrict__ out, int out_pitch,
-                         int C_pad) {
+                         int C_pad, unsigned *amax_out) {
     __shared__ float tile[32][33];
+    __shared__ float s_amax[4];
+    float amax = 0.f;
     const long n = blockIdx.z;
     const long px0 = (long)blockIdx.x * 32;
     const int c0 = blockIdx.y * 32;
@@ -192,6 +232,7 @@ nchw_to_nhwc_tile_kernel(const float *__restrict__ in, int C, long HW, float *__
         const int c = c0 + r;
         const long px = px0 + tx;
         tile[r][tx] = (c < C && px < HW) ? in[(n * C + c) * HW + px] : 0.f;
+        amax = fmaxf(amax, fabsf(tile[r][tx]));
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
@@ -199,6 +240,7 @@ nchw_to_nhwc_tile_kernel(const float *__restrict__ in, int C, long HW, float *__
         const int c = c0 + tx;
         if (px < HW && c < C_pad) out[(n * HW + px) * out_pitch + c] = tile[tx][r];
     }
+    if (amax_out != nullptr) tsod_amax_commit(amax_out, amax, s_amax, threadIdx.x, 256);
 }
 
 __global__ void __launch_bounds__(256)
@@ -229,9 +271,11 @@ nhwc_to_nchw_tile_kernel(const float *__restrict__ in, int C, long HW, int in_pi
 __global__ void __launch_bounds__(256)
 gconv3x3_kernel(const float *__restrict__ in, int N, int H, int W, int C, int in_pitch, int cpg, const float *__restrict__ w,
                 const float *__restrict__ scale, const float *__restrict__ shift, int stride, float neg_slope, float act_hi,
-                int OH, int OW, float *__restrict__ out, int out_pitch) {
+                int OH, int OW, float *__restrict__ out, int out_pitch, unsigned *amax_out) {
     const int quads = C >> 2;
     const long total = (long)N * OH * OW * quads;
+    float amax = 0.f;
+    __shared__ float s_amax[4];
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int q = (int)(t % quads);
         long u = t / quads;
@@ -265,9 +309,11 @@ gconv3x3_kernel(const float *__restrict__ in, int N, int H, int W, int C, int in
         for (int o = 0; o < 4; ++o) {
             const float v = acc[o] * (scale ? scale[co + o] : 1.f) + (shift ? shift[co + o] : 0.f);
             rp[o] = fminf(fmaxf(v, 0.f) + neg_slope * fminf(v, 0.f), act_hi);
+            amax = fmaxf(amax, fabsf(rp[o]));
         }
         *reinterpret_cast<float4 *>(out + (((long)n * OH + oh) * OW + ow) * out_pitch + co) = r;
     }
+    if (amax_out != nullptr) tsod_amax_commit(amax_out, amax, s_amax, threadIdx.x, 256);
 }
 
 inline int grid_for(long total, int threads, int cap) {
@@ -296,7 +342,15 @@ extern "C" int tsod_dwconv3x3_f32(const float *in, int32_t N, int32_t H, int32_t
                                   int32_t in_off, const float *w, const float *scale, const float *shift,
                                   int32_t stride, int32_t relu, float *out, int32_t out_pitch, int32_t out_off,
                                   tsod_stream_t stream) {
+    return tsod_dwconv3x3_amax_f32(in, N, H, W, C, in_pitch, in_off, w, scale, shift, stride, relu, out, out_pitch, out_off, nullptr, stream);
+}
+
+extern "C" int tsod_dwconv3x3_amax_f32(const float *in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_pitch,
+                                       int32_t in_off, const float *w, const float *scale, const float *shift,
+                                       int32_t stride, int32_t relu, float *out, int32_t out_pitch, int32_t out_off,
+                                       uint32_t *amax_out, tsod_stream_t stream) {
     TSOD_REQUIRE(in && w && out, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE((amax_out == nullptr || (reinterpret_cast<uintptr_t>(amax_out) & 63u) == 0), TSOD_ERR_ALIGNMENT);
     TSOD_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2), TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE((C & 3) == 0 && (in_pitch & 3) == 0 && (out_pitch & 3) == 0 && (in_off & 3) == 0 && (out_off & 3) == 0,
                  TSOD_ERR_ALIGNMENT);
@@ -316,7 +370,7 @@ extern "C" int tsod_dwconv3x3_f32(const float *in, int32_t N, int32_t H, int32_t
         TSOD_REQUIRE((total + 255) / 256 <= 0x7FFFFFFFl, TSOD_ERR_UNSUPPORTED);                                        \
         hipLaunchKernelGGL((dwconv3x3_kernel<S, O, RR>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,          \
                            tsod_stream(stream), in, N, H, W, C / 4, in_pitch, in_off, w, scale, shift, relu, OH, OW,   \
-                           out, out_pitch, out_off);                                                                   \
+                           out, out_pitch, out_off, amax_out);                                                         \
     } while (0)
     if (stride == 1) {
         if (threads_for(8, 4) >= want) TSOD_DW(1, 4, 8);
@@ -335,7 +389,15 @@ extern "C" int tsod_dwconv3x3_f32(const float *in, int32_t N, int32_t H, int32_t
 extern "C" int tsod_gconv3x3_f32(const float *in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_pitch,
                                  int32_t groups, const float *w, const float *scale, const float *shift, int32_t stride,
                                  int32_t act, float slope, float *out, int32_t out_pitch, tsod_stream_t stream) {
+    return tsod_gconv3x3_amax_f32(in, N, H, W, C, in_pitch, groups, w, scale, shift, stride, act, slope, out, out_pitch, nullptr, stream);
+}
+
+extern "C" int tsod_gconv3x3_amax_f32(const float *in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_pitch,
+                                      int32_t groups, const float *w, const float *scale, const float *shift, int32_t stride,
+                                      int32_t act, float slope, float *out, int32_t out_pitch, uint32_t *amax_out,
+                                      tsod_stream_t stream) {
     TSOD_REQUIRE(in && w && out, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE((amax_out == nullptr || (reinterpret_cast<uintptr_t>(amax_out) & 63u) == 0), TSOD_ERR_ALIGNMENT);
     TSOD_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && groups > 0 && C % groups == 0 && (stride == 1 || stride == 2),
                  TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(act >= TSOD_ACT_NONE && act <= TSOD_ACT_RELU, TSOD_ERR_INVALID_ARG);
@@ -348,34 +410,60 @@ extern "C" int tsod_gconv3x3_f32(const float *in, int32_t N, int32_t H, int32_t 
     const float neg_slope = act == TSOD_ACT_NONE ? 1.f : (act == TSOD_ACT_PRELU ? slope : 0.f);
     const float act_hi = act == TSOD_ACT_RELU6 ? 6.f : __builtin_huge_valf();
     hipLaunchKernelGGL(gconv3x3_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, tsod_stream(stream), in, N, H, W, C,
-                       in_pitch, cpg, w, scale, shift, stride, neg_slope, act_hi, OH, OW, out, out_pitch);
+                       in_pitch, cpg, w, scale, shift, stride, neg_slope, act_hi, OH, OW, out, out_pitch, amax_out);
     return tsod_launch_status();
 }
 
 extern "C" int tsod_gconv1x1_pair_f32(const float *in, int64_t pixels, int32_t G, int32_t in_pitch, const float *w,
                                       const float *bias, float *out, int32_t out_pitch, tsod_stream_t stream) {
+    return tsod_gconv1x1_pair_amax_f32(in, pixels, G, in_pitch, w, bias, out, out_pitch, nullptr, stream);
+}
+
+extern "C" int tsod_gconv1x1_pair_amax_f32(const float *in, int64_t pixels, int32_t G, int32_t in_pitch, const float *w,
+                                           const float *bias, float *out, int32_t out_pitch, uint32_t *amax_out,
+                                           tsod_stream_t stream) {
     TSOD_REQUIRE(in && w && out, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE((amax_out == nullptr || (reinterpret_cast<uintptr_t>(amax_out) & 63u) == 0), TSOD_ERR_ALIGNMENT);
     TSOD_REQUIRE(pixels > 0 && G > 0 && in_pitch >= 2 * G && out_pitch >= G, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE((in_pitch & 1) == 0 && (reinterpret_cast<uintptr_t>(in) & 7u) == 0 &&
                      (reinterpret_cast<uintptr_t>(w) & 7u) == 0,
                  TSOD_ERR_ALIGNMENT);
     hipLaunchKernelGGL(gconv1x1_pair_kernel, dim3(grid_for(pixels * G, 256, 8192)), dim3(256), 0, tsod_stream(stream), in,
-                       (long)pixels, G, in_pitch, w, bias, out, out_pitch);
+                       (long)pixels, G, in_pitch, w, bias, out, out_pitch, amax_out);
     return tsod_launch_status();
 }
 
 extern "C" int tsod_nchw_to_nhwc_f32(const float *in, int32_t N, int32_t C, int32_t H, int32_t W, float *out,
                                      int32_t out_pitch, int32_t C_pad, tsod_stream_t stream) {
+    return tsod_nchw_to_nhwc_amax_f32(in, N, C, H, W, out, out_pitch, C_pad, nullptr, stream);
+}
+
+extern "C" int tsod_amax_reset(uint32_t *words, int32_t n_tensors, tsod_stream_t stream) {
+    TSOD_REQUIRE(words && n_tensors > 0, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE((reinterpret_cast<uintptr_t>(words) & 63u) == 0, TSOD_ERR_ALIGNMENT);
+    return hipMemsetAsync(words, 0, (size_t)n_tensors * TSOD_AMAX_BYTES, tsod_stream(stream)) == hipSuccess ? TSOD_OK : TSOD_ERR_LAUNCH;
+}
+
+extern "C" int tsod_absmax_f32(const float *x, int64_t n, uint32_t *amax_out, tsod_stream_t stream) {
+    TSOD_REQUIRE(x && amax_out && n > 0, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE((reinterpret_cast<uintptr_t>(amax_out) & 63u) == 0 && (reinterpret_cast<uintptr_t>(x) & 3u) == 0, TSOD_ERR_ALIGNMENT);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for((n + 3) / 4, 256, 2048)), dim3(256), 0, tsod_stream(stream), x, (long)n, amax_out);
+    return tsod_launch_status();
+}
+
+extern "C" int tsod_nchw_to_nhwc_amax_f32(const float *in, int32_t N, int32_t C, int32_t H, int32_t W, float *out,
+                                          int32_t out_pitch, int32_t C_pad, uint32_t *amax_out, tsod_stream_t stream) {
     TSOD_REQUIRE(in && out, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE((amax_out == nullptr || (reinterpret_cast<uintptr_t>(amax_out) & 63u) == 0), TSOD_ERR_ALIGNMENT);
     TSOD_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && C_pad >= C && out_pitch >= C_pad, TSOD_ERR_INVALID_ARG);
     const long HW = (long)H * W;
     if (C_pad <= 4) {
         hipLaunchKernelGGL(nchw_to_nhwc_small_kernel, dim3(grid_for((long)N * HW, 256, 8192)), dim3(256), 0,
-                           tsod_stream(stream), in, N, C, HW, out, out_pitch, C_pad);
+                           tsod_stream(stream), in, N, C, HW, out, out_pitch, C_pad, amax_out);
     } else {
         TSOD_REQUIRE(N <= 65535 && (C_pad + 31) / 32 <= 65535, TSOD_ERR_UNSUPPORTED);
         hipLaunchKernelGGL(nchw_to_nhwc_tile_kernel, dim3((unsigned)((HW + 31) / 32), (C_pad + 31) / 32, N), dim3(256), 0,
-                           tsod_stream(stream), in, C, HW, out, out_pitch, C_pad);
+                           tsod_stream(stream), in, C, HW, out, out_pitch, C_pad, amax_out);
     }
     return tsod_launch_status();
 }

@@ -96,7 +96,12 @@ def weights_bf16x3(pc) -> torch.Tensor:
     return w3
 
 
-FP16X2_A_SCALE_EXP = 4     # activations are split as 2^4 * x under the fp16x2 arithmetic: |x| < 4094 (65504 / 16) is its range
+FP16X2_A_SCALE_EXP = 4     # static default (no range words): activations are split as 2^4 * x: |x| < 4094 (65504 / 16) is its range
+
+
+def new_range_flag() -> torch.Tensor:
+    """One int32 in pinned host memory (device-visible at the same address): what desc.range_flag points at."""
+    return torch.zeros(1, dtype=torch.int32).pin_memory()
 
 
 def fp16x2_activation_exp(absmax: float, headroom_bits: int = 4) -> int:
@@ -135,6 +140,7 @@ class BufferPool:
         self.device = device
         self._free: dict[int, list[torch.Tensor]] = {}
         self.total_bytes = 0
+        self.on_alloc = None                 # called with every tensor handed out (Plan: a fresh set of range words per tensor)
 
     def alloc(self, shape: Sequence[int], dtype=torch.float32) -> torch.Tensor:
         n = 1
@@ -143,9 +149,13 @@ class BufferPool:
         key = (n, dtype)
         lst = self._free.get(key)
         if lst:
-            return lst.pop().view(*shape)
-        self.total_bytes += n * (4 if dtype in (torch.float32, torch.int32) else 8)
-        return torch.empty(n, dtype=dtype, device=self.device).view(*shape)
+            t = lst.pop().view(*shape)
+        else:
+            self.total_bytes += n * (4 if dtype in (torch.float32, torch.int32) else 8)
+            t = torch.empty(n, dtype=dtype, device=self.device).view(*shape)
+        if self.on_alloc is not None:
+            self.on_alloc(t)
+        return t
 
     def release(self, t: torch.Tensor) -> None:
         self._free.setdefault((t.numel(), t.dtype), []).append(t.reshape(-1))
@@ -173,7 +183,7 @@ class ConvStep:
         if precision == _ffi.PREC_FP16X2:
             w2, e = weights_fp16x2(self.pc)
             d.a_scale_exp, d.w_scale_exp = int(self.exps.get(self.name, FP16X2_A_SCALE_EXP)), int(e)
-            d.range_flag = ptr(self.range_flag)                  # the plan's word: PlanOwner.raise_if_error reads it
+            d.range_flag = ptr(self.range_flag)                  # the owner's word: PlanOwner.raise_if_error reads it
             self.args[self.w_index] = ptr(w2)
         else:
             self.args[self.w_index] = ptr(weights_bf16x3(self.pc)) if precision == _ffi.PREC_BF16X3 else ptr(self.pc.w)
@@ -192,10 +202,54 @@ class Plan:
         self._ws_slots: list[tuple[list, int, int, int]] = []   # (args, ptr index, size index, bytes)
         self.workspace: torch.Tensor | None = None
         self.graph = None
-        # fp16x2 layers OR 1 into this word when an activation left the arithmetic's range (include/tsod.h: range_flag)
-        self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # fp16x2 layers OR 1 into this word when a launch ends with non-finite accumulators (include/tsod.h: range_flag).  A word
+        # in pinned HOST memory, written by the rare launch that has something to report and read by the host without a device
+        # round trip (PlanOwner shares ONE word among all its plans, see _cached_plan)
+        self.range_flag = new_range_flag()
         self.a_exps: dict = {}               # layer name -> fp16x2 activation exponent (calibrate_fp16x2); the owner shares ONE dict among its plans
         self.flops = 0
+        self.on_calibrated = None
+        # Range words (include/tsod.h): every tensor the pool hands out gets a fresh set; producers add their outputs' abs-max,
+        # fp16x2 convs take their activation scale from the words of their input(s) - per forward, inside the launches.
+        self.dynamic_scale = bool(self.DEFAULT_DYNAMIC_SCALE)
+        self.amax = torch.zeros(self.AMAX_SLOTS * _ffi.AMAX_BYTES // 4, dtype=torch.int32, device=self.device)
+        self._amax_slot: dict[int, int] = {}                     # storage pointer of a tensor -> its current slot
+        self._amax_used = 0
+        self.pool.on_alloc = self._new_amax_slot
+
+    # -- range words ------------------------------------------------------------------------
+    DEFAULT_DYNAMIC_SCALE = True             # False: plans built from now on use the static fp16x2 exponents (calibrate_fp16x2)
+    AMAX_SLOTS = 320                         # tensors per forward (ResNet-101: ~110, HarDNet-85: ~200); 4 KB each
+
+    def _new_amax_slot(self, t: torch.Tensor) -> None:
+        if self._amax_used >= self.AMAX_SLOTS:
+            raise TsodError("plan: more activation tensors than range-word slots")
+        self._amax_slot[t.untyped_storage().data_ptr()] = self._amax_used
+        self._amax_used += 1
+
+    def amax_ptr(self, t) -> int:
+        """Device pointer of the range words of the tensor that lives in ``t``'s storage right now (0: none / switched off)."""
+        if t is None or not self.dynamic_scale:
+            return 0
+        slot = self._amax_slot.get(t.untyped_storage().data_ptr())
+        return 0 if slot is None else self.amax.data_ptr() + slot * _ffi.AMAX_BYTES
+
+    def alias_amax(self, t: torch.Tensor, src: torch.Tensor) -> None:
+        """``t`` is a max / mean pooling of ``src``: its abs-max is bounded by src's, it shares src's words."""
+        slot = self._amax_slot.get(src.untyped_storage().data_ptr())
+        if slot is not None:
+            self._amax_slot[t.untyped_storage().data_ptr()] = slot
+
+    def clear_range_flag(self) -> None:
+        """Forget what launches issued so far reported (tuning / timing launches run on whatever the pooled buffers hold).  The
+        word lives in host memory: wait for those launches first."""
+        torch.cuda.synchronize(self.device)
+        self.range_flag.zero_()
+
+    def reset_amax(self) -> None:
+        """Zero the words in use (stream-ordered, capturable): first thing of every forward, before the input is staged."""
+        if self.dynamic_scale and self._amax_used:
+            check(lib().tsod_amax_reset(ptr(self.amax), self._amax_used, stream_ptr()), "amax_reset")
 
     # -- building ---------------------------------------------------------------------------
     def packed(self, key, make: Callable):
@@ -240,6 +294,7 @@ class Plan:
                            slope=pc.slope, res_pitch=0 if residual is None else residual.shape[3], res_off=0,
                            tile=tile, split_k=split_k, precision=precision,
                            src2=None if x2 is None else (pc.c2, x2.shape[3], 0, stride2, x2.shape[1], x2.shape[2]))
+        d.amax_in, d.amax_in2, d.amax_out = self.amax_ptr(x) or None, self.amax_ptr(x2) or None, self.amax_ptr(out) or None
         args = [byref(d), ptr(x), ptr(weights_bf16x3(pc)) if precision == _ffi.PREC_BF16X3 else ptr(pc.w), ptr(pc.scale),
                 ptr(pc.shift), ptr(residual), ptr(out), 0, 0]
         if x2 is not None:
@@ -305,9 +360,10 @@ class Plan:
             rc = fn(*args, s)
             if rc != 0:
                 check(rc, getattr(fn, "__name__", "tsod call"))
-        torch.cuda.current_stream(self.device).synchronize()
-        self.range_flag.zero_()
+        self.clear_range_flag()
         self.graph = None                                        # (a captured graph has the old exponents baked in)
+        if self.on_calibrated is not None:
+            self.on_calibrated()                                 # (the owner: graphs captured at detector level are stale too)
         return seen
 
     # -- running ----------------------------------------------------------------------------
@@ -468,7 +524,7 @@ class Plan:
             results = self._refine_in_sequence(shortlist, results, big, reps=5, verbose=verbose)
         del big, bigs
         self.finalize()
-        self.range_flag.zero_()      # (timing launches ran on whatever the pooled buffers held: not a forward's verdict)
+        self.clear_range_flag()      # (timing launches ran on whatever the pooled buffers held: not a forward's verdict)
         return results
 
     def _refine_in_sequence(self, shortlist, results, big, reps, verbose):
@@ -617,7 +673,7 @@ def refine_in_flight(plans, shortlist, rounds: int = 4, verbose: bool = False):
     if verbose:
         print(f"  in flight: {changed} of {L} picks changed; conv time per forward with {n} staggered streams {base / rounds / n * 1e3:.1f} us")
     for pl in plans:
-        pl.range_flag.zero_()                                        # (see Plan.autotune)
+        pl.clear_range_flag()                                        # (see Plan.autotune)
     return plans[0].export_tiles()
 
 
@@ -655,16 +711,23 @@ class PlanOwner:
         return self
 
     def raise_if_error(self):
-        """Surface a range violation of the fp16x2 arithmetic in any plan of this owner (one device sync per plan that has
-        fp16x2 layers): the forward that set it produced garbage in the layers concerned."""
-        for plan in list(self.__dict__.get("_plans", {}).values()):
-            flag = getattr(plan, "range_flag", None)
-            if flag is not None and any(int(st.desc.precision) == _ffi.PREC_FP16X2 for st in plan.conv_steps) and int(flag.item()) != 0:
-                with torch.inference_mode():
-                    flag.zero_()
-                raise TsodError("fp16x2: a conv layer ended with non-finite accumulators - an activation beyond +-"
-                                f"{65504 // (1 << FP16X2_A_SCALE_EXP)} (or non-finite input); its outputs are garbage. Re-tune with "
-                                "precisions=(0, 1) (bf16x3 / f32) for this model")
+        """Surface what the fp16x2 launches of ANY plan of this owner reported since the last call (evicted plans included:
+        the word belongs to the owner): a launch that ended with non-finite accumulators - non-finite input, or, for a conv
+        without range words, an activation beyond the static exponent's range; its outputs are garbage.  Waits for the device
+        (the word is host memory written by the launches), then one host read."""
+        flag = self.__dict__.get("_range_flag")
+        if flag is None:
+            return
+        torch.cuda.synchronize()
+        if int(flag[0]) != 0:
+            flag.zero_()
+            raise TsodError("fp16x2: a conv layer ended with non-finite accumulators - non-finite input (or, without range words, "
+                            f"an activation beyond +-{65504 // (1 << FP16X2_A_SCALE_EXP)}); its outputs are garbage")
+
+    def range_flag_raised(self) -> bool:
+        """The word itself, without waiting for anything: True once a launch that has COMPLETED reported (serving.result())."""
+        flag = self.__dict__.get("_range_flag")
+        return flag is not None and int(flag[0]) != 0
 
     def _init_plan_owner(self):
         self.__dict__["_plans"] = OrderedDict()
@@ -673,9 +736,14 @@ class PlanOwner:
         self.register_load_state_dict_post_hook(_invalidate_after_load)
 
     def invalidate_packed(self):
-        """Drop compiled plans and packed weights (call after changing weights in place)."""
+        """Drop compiled plans and packed weights (call after changing weights in place).  The fp16x2 activation exponents
+        calibrated for the old weights go with them (in place: plans that are still referenced see the change)."""
         self.__dict__["_plans"] = OrderedDict()
         self.__dict__["_packed_cache"] = {}
+        self.__dict__.setdefault("_a_exps", {}).clear()
+        self.__dict__["weights_version"] = self.__dict__.get("weights_version", 0) + 1
+
+    def _bump_version(self):
         self.__dict__["weights_version"] = self.__dict__.get("weights_version", 0) + 1
 
     def _apply(self, fn, *a, **k):
@@ -693,12 +761,19 @@ class PlanOwner:
         if plan is None:
             plan = plans[key] = build()
             shared = self.__dict__.setdefault("_a_exps", {})      # fp16x2 activation exponents by layer name, for every plan of this owner
+            flag = self.__dict__.get("_range_flag")
+            if flag is None and isinstance(plan, Plan):
+                flag = self.__dict__["_range_flag"] = plan.range_flag      # ONE range word per owner: survives plan eviction, one read
             if isinstance(plan, Plan):
                 plan.a_exps = shared
+                plan.range_flag = flag
+                plan.on_calibrated = self._bump_version           # (a graph captured at detector level holds the old exponents)
             for st in getattr(plan, "conv_steps", ()):
                 st.exps = shared
+                st.range_flag = flag
                 if int(st.desc.precision) == _ffi.PREC_FP16X2:    # (built in that arithmetic: choose() ran before the dict was shared)
                     st.desc.a_scale_exp = int(shared.get(st.name, FP16X2_A_SCALE_EXP))
+                    st.desc.range_flag = ptr(flag)
             while len(plans) > max(1, int(self.max_plans)):
                 plans.popitem(last=False)
         else:
@@ -750,11 +825,15 @@ def stage_input(plan: "Plan", x) -> None:
     (tsod_nchw_to_nhwc_f32), ``NHWC4Images`` are already in layout (no launch at all when they were written straight
     into ``plan.input_nhwc``, see ``input_buffer`` of the backbones)."""
     from ._ffi import NHWC4Images
+    plan.reset_amax()                                   # the range words of this forward start from zero
+    a_in = plan.amax_ptr(plan.input_nhwc)
     if isinstance(x, NHWC4Images):
         if x.data.data_ptr() != plan.input_nhwc.data_ptr():
             with torch.inference_mode():                # the plan's buffers may have been allocated under inference mode
                 plan.input_nhwc.copy_(x.data)
+        if a_in:                                        # (nobody of ours produced these pixels: one pass for their range)
+            check(lib().tsod_absmax_f32(ptr(plan.input_nhwc), plan.input_nhwc.numel(), a_in, stream_ptr()), "absmax")
         return
     x = x.contiguous()
     N, _, H, W = x.shape
-    check(lib().tsod_nchw_to_nhwc_f32(ptr(x), N, 3, H, W, ptr(plan.input_nhwc), 4, 4, stream_ptr()), "nchw_to_nhwc")
+    check(lib().tsod_nchw_to_nhwc_amax_f32(ptr(x), N, 3, H, W, ptr(plan.input_nhwc), 4, 4, a_in or None, stream_ptr()), "nchw_to_nhwc")

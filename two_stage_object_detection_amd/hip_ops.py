@@ -178,7 +178,7 @@ def _w3_for(w_packed: torch.Tensor) -> torch.Tensor:
 def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_logical=None, scale=None, shift=None,
                 residual=None, act=ACT_NONE, slope=0.0, segs=None, out=None, out_off=0, tile=0, split_k=0,
                 precision=0, x2=None, stride2=1, x2_off=0, w3=None, a_scale_exp=4, w2=None, w_scale_exp=None,
-                range_flag=None) -> torch.Tensor:
+                range_flag=None, amax_in=None, amax_in2=None, amax_out=None) -> torch.Tensor:
     """Implicit-GEMM convolution on an NHWC tensor [N,H,W,P].  ``w_packed`` is [Cout,KH,KW,Cin]
     (see pack_conv_weight); ``kw_logical`` is the filter width before zero-tap padding (it fixes OW).
     ``segs`` = [(channel offset, length), ...] inside the P-wide pixel (default: the first Cin
@@ -190,7 +190,9 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
     ``precision`` = bf16x3 instead of the wrapper's own cache.  ``precision`` = fp16x2: activations are split as
     2^``a_scale_exp`` * x (|that| must stay below 65504), ``w2`` / ``w_scale_exp`` = the fp16x2 weight image and the exponent it
     was packed with (made on the spot from ``w_packed`` when not given); ``range_flag``: an int32 device word the launch sets to 1
-    when an activation left that range."""
+    when an activation left that range.  ``amax_out`` / ``amax_in`` / ``amax_in2``: range words (``new_amax_words``; a tensor or
+    a raw device pointer): the launch adds its outputs' abs-max to ``amax_out``; an fp16x2 launch takes its activation exponent
+    from ``amax_in`` (and ``amax_in2`` for ``x2``) instead of ``a_scale_exp``."""
     require_cuda(x, "conv2d")
     assert x.is_contiguous() and w_packed.is_contiguous()
     N, H, W, P = x.shape
@@ -218,6 +220,8 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
             w2 = pack_conv_weight_fp16x2(w_packed, w_scale_exp)
         d.a_scale_exp, d.w_scale_exp = int(a_scale_exp), int(w_scale_exp)
         d.range_flag = ptr(range_flag)                            # optional int32 [1] device tensor: 1 = an activation left the range
+        d.amax_in, d.amax_in2 = _word_ptr(amax_in), _word_ptr(amax_in2)
+    d.amax_out = _word_ptr(amax_out)
     ws_bytes = lib().tsod_conv2d_workspace_bytes(byref(d))
     ws = CONV_ARENA.get(x.device, ws_bytes) if ws_bytes else None
     # bf16x3 / fp16x2 read their pre-split weight images
@@ -225,6 +229,31 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
     check(lib().tsod_conv2d_dual_f32(byref(d), ptr(x), ptr(x2), ptr(w_arg), ptr(scale), ptr(shift), ptr(residual), ptr(out),
                                      ptr(ws), ws_bytes, stream_ptr()), "conv2d")
     return out
+
+
+def _word_ptr(w):
+    """None / a raw device pointer / a tensor of range words -> what the descriptor takes."""
+    if w is None:
+        return None
+    return (int(w) if not isinstance(w, torch.Tensor) else w.data_ptr()) or None
+
+
+def new_amax_words(device, n: int = 1) -> torch.Tensor:
+    """Zeroed range words for ``n`` tensors (include/tsod.h "Range words"): int32 [n, AMAX_BYTES / 4]; row i is one tensor's."""
+    return torch.zeros((n, _ffi.AMAX_BYTES // 4), dtype=torch.int32, device=device)
+
+
+def amax_value(words: torch.Tensor) -> float:
+    """The abs-max a set of range words holds (host read; tests and diagnostics)."""
+    w = words.reshape(-1)[:: _ffi.AMAX_STRIDE // 4][: _ffi.AMAX_WORDS]
+    return float(w.max().view(1).view(torch.float32))
+
+
+def absmax(x: torch.Tensor, words: torch.Tensor) -> torch.Tensor:
+    """Add the abs-max of ``x`` to ``words`` (tsod_absmax_f32)."""
+    require_cuda(x, "absmax")
+    check(lib().tsod_absmax_f32(ptr(x), x.numel(), ptr(words), stream_ptr()), "absmax")
+    return words
 
 
 def tune_conv(x: torch.Tensor, w_packed: torch.Tensor, reps: int = 5, precisions=(0, 1), **kw) -> tuple[int, int, int]:

@@ -230,8 +230,8 @@ class HarDNetFeatureExtraction(PlanOwner, nn.Module):
         def emit_dw(src, src_off, C, conv, bn, stride, relu, dst, dst_off, name):
             w33, scale, shift, cp = plan.packed(name, lambda: self._dw_params(conv, bn, device))
             n, h, w_, P = src.shape
-            plan.call(L.tsod_dwconv3x3_f32, ptr(src), n, h, w_, cp, P, src_off, ptr(w33), ptr(scale), ptr(shift), stride,
-                      1 if relu else 0, ptr(dst), dst.shape[3], dst_off, keep=(src, dst, w33, scale, shift))
+            plan.call(L.tsod_dwconv3x3_amax_f32, ptr(src), n, h, w_, cp, P, src_off, ptr(w33), ptr(scale), ptr(shift), stride,
+                      1 if relu else 0, ptr(dst), dst.shape[3], dst_off, plan.amax_ptr(dst) or None, keep=(src, dst, w33, scale, shift))
 
         # --- stem: 3x3 s2 conv (3 -> c0, input padded to 4 channels), 1x1 conv, dw3x3 s2
         m0, m1, m2 = mods[0], mods[1], mods[2]
@@ -312,14 +312,15 @@ class HarDNetFeatureExtraction(PlanOwner, nn.Module):
                     m.weight.detach().float().view(G, 2).contiguous().to(device),
                     None if m.bias is None else m.bias.detach().float().to(device)))
                 dst = plan.pool.alloc((N, h, w, G))
-                plan.call(L.tsod_gconv1x1_pair_f32, ptr(cur), N * h * w, G, cur.shape[3], ptr(wg), ptr(bias), ptr(dst), G,
-                          keep=(cur, dst, wg, bias))
+                plan.call(L.tsod_gconv1x1_pair_amax_f32, ptr(cur), N * h * w, G, cur.shape[3], ptr(wg), ptr(bias), ptr(dst), G,
+                          plan.amax_ptr(dst) or None, keep=(cur, dst, wg, bias))
                 plan.pool.release(cur)
                 cur, cur_off, cur_C = dst, 0, G
                 i += 1
             else:
                 raise TsodError(f"no HIP lowering for base.{i}: {type(m).__name__}")
         plan.output_nhwc = cur
+        plan.output_amax = plan.amax_ptr(cur)
         return plan.finalize()
 
     def forward(self, x):

@@ -90,8 +90,8 @@ class _ResidualBlock(nn.Module):
         w, sc, sh = plan.packed(name, make)
         N, H, W, _ = cur.shape
         out = plan.pool.alloc((N, (H - 1) // stride + 1, (W - 1) // stride + 1, C))
-        plan.call(lib().tsod_gconv3x3_f32, ptr(cur), N, H, W, C, cur.shape[3], groups, ptr(w), ptr(sc), ptr(sh), stride,
-                  ACT_PRELU, float(slope), ptr(out), C, keep=(cur, out, w, sc, sh))
+        plan.call(lib().tsod_gconv3x3_amax_f32, ptr(cur), N, H, W, C, cur.shape[3], groups, ptr(w), ptr(sc), ptr(sh), stride,
+                  ACT_PRELU, float(slope), ptr(out), C, plan.amax_ptr(out) or None, keep=(cur, out, w, sc, sh))
         if cur is not x:
             plan.pool.release(cur)
         return out
@@ -178,6 +178,7 @@ class ResNet(PlanOwner, nn.Module):
         ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
         cur = plan.pool.alloc((N, ph, pw, 64))
         plan.call(lib().tsod_maxpool3x3s2_f32, ptr(s_out), N, oh, ow, 64, 64, ptr(cur), 64, keep=(s_out, cur))
+        plan.alias_amax(cur, s_out)          # range words: max |pooled| <= max |stem output|
         plan.pool.release(s_out)
         for li in range(1, 5):
             for bi, blk in enumerate(getattr(self, f"layer{li}")):
@@ -185,6 +186,7 @@ class ResNet(PlanOwner, nn.Module):
                 plan.pool.release(cur)
                 cur = nxt
         plan.output_nhwc = cur
+        plan.output_amax = plan.amax_ptr(cur)
         return plan.finalize()
 
     def forward(self, x):

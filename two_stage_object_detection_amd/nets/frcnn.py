@@ -110,6 +110,61 @@ class FasterRCNN(nn.Module):
             fc7 = torch.randn(x.shape[0] * n_post, self.head.cls_loc.in_features, device=x.device)
             return rpn_choice, self.head.autotune(fc7)
 
+    def tune(self, example, precisions=(0, 1, 2), in_flight=1, schedules=("serial", "in_flight"), splits=None, in_sequence=None,
+             in_flight_refine=None, reps=3, heads=True, verbose=False):
+        """Autotune every GEMM of the forward for ``example``'s geometry ([B,3,H,W] on the GPU) and pin the result: per conv
+        layer the fastest (tile, K-slice schedule, arithmetic) among ``precisions`` (0 f32 MFMA, 1 bf16x3, 2 fp16x2 - all three
+        f32-accurate; the fp16x2 scale follows every tensor per forward through its range words, so no calibration pass and no
+        input range is involved), plus the fused RPN conv and the fused head GEMM.  A speed choice only.
+
+        ``schedules``: "serial" = one forward at a time (candidates timed alone; below batch 4 the five fastest of a layer are
+        timed again inside the conv sequence, ``in_sequence``); "in_flight" (only with ``in_flight`` > 1) = the objective of
+        ``serving.InFlightDetector(depth=in_flight)``: candidates timed as that many copies side by side, then
+        (``in_flight_refine``, default 3 below batch 4) re-tried with every slot's stream running the whole conv sequence.
+        Returns the tables as plain JSON-able data {"serial": [...], "in_flight": [...], "heads": {...}} - feed it back through
+        ``import_tuning`` (another process, another rank) or ``InFlightDetector(tiles=...)``.  Afterwards the plan of slot 0
+        runs the serial table when that was tuned, else the in-flight one."""
+        from ..engine import refine_in_flight
+        require_cuda(example, "FasterRCNN.tune")
+        B = example.shape[0]
+        in_sequence = (5 if B < 4 else 0) if in_sequence is None else in_sequence
+        in_flight_refine = (3 if B < 4 else 0) if in_flight_refine is None else in_flight_refine
+        if splits is None and B >= 4:
+            splits = [1, -1, -2, 2, 4]       # large M: tiles outnumber the chip's slots many times; deep K-slicing never wins there
+        table = {}
+        with torch.inference_mode():
+            self(example)                                           # builds the plan; leaves real activations (and range words) behind
+            plan = self.extractor._plan_for(example)
+            if "serial" in schedules:
+                plan.autotune(reps=reps, verbose=verbose, splits=splits, concurrent=1, precisions=precisions, in_sequence=in_sequence)
+                table["serial"] = plan.export_tiles()
+            if "in_flight" in schedules and in_flight > 1:
+                plan.autotune(reps=reps, verbose=False, splits=splits, concurrent=max(2, in_flight), precisions=precisions,
+                              keep_shortlist=in_flight_refine)
+                table["in_flight"] = plan.export_tiles()
+                if in_flight_refine > 0 and plan.last_shortlist:
+                    slot_plans = [plan]
+                    for sl in range(1, in_flight):
+                        self(example, slot=sl)
+                        slot_plans.append(self.extractor._plan_for(example, sl))
+                        slot_plans[-1].import_tiles(table["in_flight"])
+                    table["in_flight"] = refine_in_flight(slot_plans, plan.last_shortlist, verbose=verbose)
+            if not table:
+                raise TsodError("FasterRCNN.tune: nothing to tune (schedules / in_flight)")
+            plan.import_tiles(table.get("serial") or table["in_flight"])
+            if heads:
+                self.autotune_heads(example)
+                table["heads"] = self.head_choices()
+        return table
+
+    def import_tuning(self, table, example, schedule="serial", slot=0):
+        """Pin a table made by ``tune`` (same model, same input geometry; e.g. rank 0's on every rank) in the plan of ``slot``."""
+        require_cuda(example, "FasterRCNN.import_tuning")
+        self.set_head_choices(table.get("heads"))
+        with torch.inference_mode():
+            self(example, slot=slot)
+            self.extractor._plan_for(example, slot).import_tiles(table.get(schedule) or table["serial"])
+
     def head_choices(self):
         """The pinned (tile, K-slice schedule, arithmetic) choices of the two GEMMs outside the backbone plan as plain data
         (JSON-able): {"rpn": {"NxHxW": [tile, split_k, precision]}, "head": {"M": [...]}} - what ``autotune_heads`` found,

@@ -30,18 +30,22 @@ class InFlightDetector:
     behind the graph (e.g. the all-gather of the records in a data-parallel job)."""
 
     def __init__(self, model, example: torch.Tensor, depth: int = 4, autotune: bool = False, tiles=None):
+        """``tiles``: a table from ``FasterRCNN.tune`` (the dict, or one of its per-schedule lists); ``autotune`` = tune here, with
+        this server's overlap as the objective."""
         require_cuda(example, "InFlightDetector")
         if depth < 1:
             raise TsodError("InFlightDetector: depth must be >= 1")
         self.model, self.depth, self.device = model, depth, example.device
         with torch.inference_mode():
+            if tiles is None and autotune:
+                tiles = model.tune(example, in_flight=depth, schedules=("in_flight",) if depth > 1 else ("serial",))
+            if isinstance(tiles, dict):
+                model.set_head_choices(tiles.get("heads"))
+                tiles = tiles.get("in_flight" if depth > 1 else "serial") or tiles.get("serial")
             model(example)                                               # builds slot 0's plan
             plan0 = model.extractor._plan_for(example, 0)
             if tiles is not None:
                 plan0.import_tiles(tiles)
-            elif autotune:
-                plan0.autotune(concurrent=depth if depth > 1 else 1, precisions=(0, 1))   # objective = this server's overlap
-                model.autotune_heads(example)
             self.tiles = plan0.export_tiles()
             for s in range(1, depth):                                    # the same tile choices in every slot's plan
                 model(example, slot=s)
@@ -81,6 +85,11 @@ class InFlightDetector:
         if self._ticket_of[slot] != ticket:
             raise TsodError(f"InFlightDetector: ticket {ticket} is no longer resident (its slot was reused)")
         self._done[slot].synchronize()
+        # the conv launches' range word is host memory (engine.new_range_flag): a plain read, no device round trip.  A set word
+        # means SOME forward that has completed on this detector ran an fp16x2 layer into non-finite accumulators (non-finite
+        # input): this step's outputs may be garbage - never hand them out as valid.
+        if self.model.extractor.range_flag_raised():
+            self.model.extractor.raise_if_error()
         return self._outputs[slot]
 
     def drain(self) -> None:
