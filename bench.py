@@ -188,6 +188,29 @@ def conv_sequence_time(plan, reps=10):
     return ms
 
 
+def conv_in_sequence_times(plan, reps=7):
+    """Per conv launch: HIP-event time (ms, median over `reps` passes) INSIDE one pass over the conv sequence - every launch
+    bracketed by its own pair of events while the sequence runs in forward order.  The per-layer companion of
+    conv_sequence_time (the isolated figure of conv_event_times re-runs one launch on hot operands and reads up to 3x high on
+    the HBM-bound layer1 launches, whose input then comes from HBM instead of being written just before)."""
+    from two_stage_object_detection_amd._ffi import stream_ptr
+    s = stream_ptr()
+    n = len(plan.conv_steps)
+    samples = [[] for _ in range(n)]
+    for r in range(reps + 1):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for (e0, e1), st in zip(ev, plan.conv_steps):
+            e0.record()
+            st.fn(*st.args, s)
+            e1.record()
+        ev[-1][1].synchronize()
+        if r:                                                   # (the first pass warms up)
+            for i, (e0, e1) in enumerate(ev):
+                samples[i].append(e0.elapsed_time(e1))
+    plan.clear_range_flag()
+    return [statistics.median(v) for v in samples]
+
+
 def cpu_baseline(sd, backbone, x_cpu, reps):
     """(the oracle's outputs on x_cpu, the cpu_baseline object).  The outputs are what `parity` checks the timed plans against:
     the line validates what it times."""
@@ -226,7 +249,7 @@ def conv_algorithmic_bytes(plan):
     return sum(step_algorithmic_bytes(st) for st in plan.conv_steps)
 
 
-def dump_layers(plan, path, conv_ms=None):
+def dump_layers(plan, path, conv_ms=None, seq_ms=None):
     """Per conv launch of the plan, in launch order: what scripts/summarize_pmc.py needs to put names, algorithmic bytes and
     K-slice slab bytes beside the per-dispatch counters."""
     from ctypes import byref
@@ -239,7 +262,8 @@ def dump_layers(plan, path, conv_ms=None):
                      "tile": TILE_NAMES[int(d.tile)], "split_k": int(d.split_k), "precision": int(d.precision),
                      "slab_bytes": max(0, ws - 256 * 1024) if ws else 0, "M": int(d.N * d.OH * d.OW), "Cout": int(d.Cout),
                      "K": int(d.KH * d.KW * sum(d.seg_len[j] for j in range(d.n_seg)) + max(0, int(d.c2))),
-                     "event_us": None if conv_ms is None else round(conv_ms[i] * 1e3, 2)})
+                     "seq_us": None if seq_ms is None else round(seq_ms[i] * 1e3, 2),      # inside the conv sequence (the one to quote)
+                     "event_us": None if conv_ms is None else round(conv_ms[i] * 1e3, 2)})   # isolated repeats on hot operands
     json.dump(rows, open(path, "w"), indent=0)
 
 
@@ -600,7 +624,7 @@ def main(argv=None):
         conv_ms = conv_event_times(plan)
         conv_seq_ms = conv_sequence_time(plan)
         if args.dump_layers and rank == 0:
-            dump_layers(plan, args.dump_layers, conv_ms)
+            dump_layers(plan, args.dump_layers, conv_ms, conv_in_sequence_times(plan))
         conv_flops = sum(st.flops for st in plan.conv_steps)
         algo_bytes = conv_algorithmic_bytes(plan)
         precs = [int(st.desc.precision) for st in plan.conv_steps]

@@ -6,6 +6,13 @@
 # profiled process contains tuning launches.  Under rocprofv3 the program itself (python3) follows `--`.
 tag=$1; name=$2; shift 2
 R=$GRAFT_REPO_ROOT
+# batch / backbone of the workload (for the summary's algorithmic-bytes column)
+BATCH=1; BACKBONE=resnet50; prev=""
+for a in "$@"; do
+  [ "$prev" = "--batch" ] && BATCH=$a
+  [ "$prev" = "--backbone" ] && BACKBONE=$a
+  prev=$a
+done
 O=$R/gpurun_out/prof_${tag}_$name
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -26,7 +33,7 @@ for pass in "sq:SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_
 done
 cd $R
 python3 scripts/summarize_trace.py $(ls $O/trace_serial/*/*kernel_trace.csv) 20 > $O/serial_kernel_trace_summary.md
-python3 scripts/summarize_pmc.py "Round ${tag#r} ($name)" $O/pmc_sq $O/pmc_fetch $O/pmc_write --layers $O/layers.json --tcc $O/pmc_tcc --workload "$name: bench.py $*" > $O/pmc_summary.md
+python3 scripts/summarize_pmc.py "Round ${tag#r} ($name)" $O/pmc_sq $O/pmc_fetch $O/pmc_write --layers $O/layers.json --tcc $O/pmc_tcc --workload "$name: bench.py $*" --batch $BATCH --backbone $BACKBONE > $O/pmc_summary.md
 grep "^{" $O/trace_serial.log | tail -1 > $O/bench_serial_under_rocprof.json
 cp $(ls $O/trace_serial/*/*kernel_stats.csv) $O/serial_rocprofv3_kernel_stats.csv
 if [ "$name" = "b1" ]; then

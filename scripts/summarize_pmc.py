@@ -15,11 +15,16 @@ def short(n):
 
 
 def arith(k):
-    """conv_igemm_kernel<BM, BN, WM, WN, MINW, NBUF, BK, PREC>: PREC 1 = bf16x3"""
-    if 'conv_dma' in k:
-        return 'bf16x3 (LDS-DMA)'
+    """The arithmetic is the template's LAST argument in both kernel families:
+    conv_igemm_kernel<BM, BN, WM, WN, MINW, NBUF, BK, PREC> (8 arguments; fewer = the defaults = f32): PREC 0 f32, 1 bf16x3, 2 fp16x2;
+    conv_dma_kernel<BM, BK, WAVES_K, S, BALANCED, WAVES_N, NPL> (7 arguments): NPL 3 = bf16x3, 2 = fp16x2."""
     m = re.search(r'<([^>]*)>', k)
-    return 'bf16x3' if m and m.group(1).replace(' ', '').split(',')[-1] == '1' and len(m.group(1).split(',')) == 8 else 'f32'
+    args = m.group(1).replace(' ', '').split(',') if m else []
+    if 'conv_dma' in k:
+        return {'2': 'fp16x2 (LDS-DMA)', '3': 'bf16x3 (LDS-DMA)'}.get(args[-1] if len(args) == 7 else '3', 'bf16x3 (LDS-DMA)')
+    if len(args) == 8:
+        return {'0': 'f32', '1': 'bf16x3', '2': 'fp16x2'}.get(args[-1], 'f32')
+    return 'f32'
 
 
 def load(d):
@@ -39,6 +44,8 @@ ap.add_argument("label"); ap.add_argument("sq"); ap.add_argument("fetch"); ap.ad
 ap.add_argument("--layers", default=None, help="bench.py --dump-layers JSON: adds the per-layer table of the last forward")
 ap.add_argument("--tcc", default=None, help="a fourth pass with TCC_HIT_sum TCC_MISS_sum (L2 hit rate per layer)")
 ap.add_argument("--workload", default="B=1, 3x800x1333, ResNet-50")
+ap.add_argument("--batch", type=int, default=1, help="images per forward of the profiled workload: scales the algorithmic-MB column")
+ap.add_argument("--backbone", default="resnet50")
 A = ap.parse_args()
 label = A.label
 sq, dsq = load(A.sq); fe, dfe = load(A.fetch); wr, dwr = load(A.write)
@@ -52,7 +59,8 @@ clock_meas = sum(g) / 8 / (sum(d) * 1e-6) if d else 2.4e9
 clock = min(clock_meas, 2.4e9)
 print("## Matrix-core utilisation of the conv GEMMs (pass 1: SQ counters)\n")
 print("`MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x duration x 2.4 GHz).  The template's last argument is the")
-print("arithmetic: 0 / absent = f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16x3 (v_mfma_f32_32x32x16_bf16, six per f32 product).\n")
+print("arithmetic.  `conv_igemm_kernel<..., PREC>`: 0 / absent = f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16x3 (v_mfma_f32_32x32x16_bf16,")
+print("six per f32 product), 2 = fp16x2 (v_mfma_f32_32x32x16_f16, three per f32 product); `conv_dma_kernel<..., NPL>`: 3 = bf16x3, 2 = fp16x2.\n")
 print("| kernel | arithmetic | dispatches | avg us | MFMA busy | SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES | SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE |")
 print("|---|---|---:|---:|---:|---:|---:|")
 tot = collections.defaultdict(lambda: [0.0, 0.0])
@@ -90,10 +98,18 @@ for a, (m, c) in tot.items():
 print("\n## HBM traffic of the memory-bound kernels (passes 2 and 3: FETCH_SIZE, WRITE_SIZE)\n")
 print("| kernel | avg us | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM MB = (2*FETCH+WRITE)*1024/1e6 | achieved GB/s (PMC bytes / time) | algorithmic MB (DESIGN.md section 4) |")
 print("|---|---:|---:|---:|---:|---:|---:|")
-alg = {'maxpool3x3s2_kernel': 85.4, 'nchw_to_nhwc_small_kernel': 29.9, 'rpn_decode_kernel': 0.42, 'roi_pool_avg_kernel': 11.1,
-       'nms_mask_kernel<4, -1>': 1.18, 'nms_scan_kernel<1>': 1.13, 'sort_topk_kernel<10>': 0.11, 'detections_kernel': 0.5}
-for k in ['nchw_to_nhwc_small_kernel', 'maxpool3x3s2_kernel', 'rpn_decode_kernel', 'sort_topk_kernel<10>',
-          'nms_mask_kernel<4, -1>', 'nms_scan_kernel<1>', 'roi_pool_avg_kernel', 'detections_kernel']:
+# per IMAGE at 3x800x1333; the column is scaled by --batch.  RoI pooling: feature map + K*C*4 out, by backbone
+alg1 = {'maxpool3x3s2_kernel': 85.4, 'nchw_to_nhwc_small_kernel': 29.9,
+        'rpn_decode_kernel': 0.42 if A.backbone == 'resnet50' else 1.66,
+        'roi_pool_avg_kernel': 11.1 if A.backbone == 'resnet50' else 9.2,
+        'nms_mask_kernel<4, -1>': 1.18, 'nms_scan_kernel<1>': 1.13, 'nms_scan_kernel': 1.13, 'sort_topk_kernel<10>': 0.11, 'detections_kernel': 0.5}
+alg = {k: round(v * A.batch, 2) for k, v in alg1.items()}
+mem_kernels = ['nchw_to_nhwc_small_kernel', 'maxpool3x3s2_kernel', 'rpn_decode_kernel', 'sort_topk_kernel<10>',
+               'nms_mask_kernel<4, -1>', 'nms_scan_kernel<1>', 'nms_scan_kernel', 'roi_pool_avg_kernel', 'detections_kernel']
+# HarDNet / ResNeXt: the depthwise, pair and grouped kernels (HBM-bound; algorithmic bytes differ per layer: not tabulated, the
+# achieved GB/s column is the figure of merit) and the top-k by rank
+mem_kernels += sorted(k for k in fe if any(t in k for t in ('dwconv3x3_kernel', 'gconv1x1_pair_kernel', 'gconv3x3_kernel', 'topk_rank_kernel', 'absmax_kernel')))
+for k in mem_kernels:
     if k not in fe:
         continue
     ds = list(fe[k].items()); ds = ds[len(ds) // 2:]
@@ -153,8 +169,8 @@ if A.layers:
     print("`HBM MB` = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / 1e6 of that dispatch; `slab MB` = the K-slice partial slabs of the chosen")
     print("schedule, counted twice (written write-through by the slices, read back by the last arriver): the part of the excess that is the")
     print("price of filling the chip by cutting K; `x alg` = HBM MB / algorithmic MB; `L2 hit` = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum).\n")
-    print("| # | layer | tile | split | us | MFMA busy | HBM MB | algorithmic MB | x alg | slab MB (w+r) | HBM - slab, x alg | L2 hit |")
-    print("|---:|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
+    print("| # | layer | tile | arithmetic | split | us | MFMA busy | HBM MB | algorithmic MB | x alg | slab MB (w+r) | HBM - slab, x alg | L2 hit |")
+    print("|---:|---|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
     tot = [0.0, 0.0, 0.0, 0.0]
     for j, L in enumerate(layers):
         if j >= len(sqr) or j >= len(fer) or j >= len(wrr):
@@ -169,7 +185,7 @@ if A.layers:
             h, m = tcr[j][2].get('TCC_HIT_sum', 0), tcr[j][2].get('TCC_MISS_sum', 0)
             hit = f"{100 * h / max(1, h + m):.0f}%"
         tot[0] += us; tot[1] += mb; tot[2] += alg_mb; tot[3] += slab
-        print(f"| {j} | {L['name']} | {L['tile']} | {L['split_k']} | {us:.1f} | {100 * mf:.1f}% | {mb:.1f} | {alg_mb:.1f} | {mb / alg_mb:.2f} | "
+        print(f"| {j} | {L['name']} | {L['tile']} | {('f32', 'bf16x3', 'fp16x2')[int(L.get('precision', 0))]} | {L['split_k']} | {us:.1f} | {100 * mf:.1f}% | {mb:.1f} | {alg_mb:.1f} | {mb / alg_mb:.2f} | "
               f"{slab:.1f} | {(mb - slab) / alg_mb:.2f} | {hit} |")
-    print(f"| | **all {len(layers)} trunk convs** | | | {tot[0]:.0f} | | {tot[1]:.0f} | {tot[2]:.0f} | {tot[1] / tot[2]:.2f} | {tot[3]:.0f} | "
+    print(f"| | **all {len(layers)} trunk convs** | | | | {tot[0]:.0f} | | {tot[1]:.0f} | {tot[2]:.0f} | {tot[1] / tot[2]:.2f} | {tot[3]:.0f} | "
           f"{(tot[1] - tot[3]) / tot[2]:.2f} | |")

@@ -62,6 +62,7 @@ def compare_detector_outputs(got, ref, atol=1e-3):
     rep["rows"] = B * R
     rep["rows_positional_mismatch"] = int(((g_rois - r_rois).abs().amax(dim=-1) > atol).sum())
     unmatched, max_roi, max_score, max_loc, cls_bad = 0, 0.0, 0.0, 0.0, 0
+    nearest_unmatched = 0.0            # how far the worst row without a partner is from the nearest free reference row
     inf = float("inf")
     for b in range(B):
         d = (g_rois[b].unsqueeze(1) - r_rois[b].unsqueeze(0)).abs().amax(-1)      # [R,R]
@@ -76,6 +77,8 @@ def compare_detector_outputs(got, ref, atol=1e-3):
             if float(row[j]) <= atol:
                 partner[i] = j
                 taken[j] = True
+            else:
+                nearest_unmatched = max(nearest_unmatched, float(row[j]))
         ok = partner >= 0
         unmatched += int((~ok).sum())
         if ok.any():
@@ -85,7 +88,7 @@ def compare_detector_outputs(got, ref, atol=1e-3):
             max_loc = max(max_loc, float((g_locs[b, gi] - r_locs[b, ri]).abs().max()))
             cls_bad += int((g_scores[b, gi].argmax(-1) != r_scores[b, ri].argmax(-1)).sum())
     rep.update(rows_unmatched=unmatched, max_abs_roi=max_roi, max_abs_score=max_score, max_abs_cls_loc=max_loc,
-               class_mismatch=cls_bad, matching="one-to-one")
+               class_mismatch=cls_bad, matching="one-to-one", nearest_unmatched=nearest_unmatched)
     top2 = r_scores.topk(2, dim=-1).values
     rep["min_top2_logit_gap"] = float((top2[..., 0] - top2[..., 1]).min())
     rep["ok"] = bool(rep["roi_indices_equal"] and unmatched == 0 and cls_bad == 0
