@@ -149,11 +149,12 @@ def launch_ranks(args, argv):
 # ----------------------------------------------------------------------------------------------- measurements
 def conv_event_times(plan, reps=5):
     """HIP-event duration of every conv launch of the plan (ms), on the launch stream."""
-    from two_stage_object_detection_amd._ffi import lib, stream_ptr
-    L = lib()
+    from two_stage_object_detection_amd._ffi import stream_ptr
     out = []
     s = stream_ptr()
-    for st in plan.conv_steps:
+    for st in plan.gemm_steps:
+        if hasattr(st, "x"):
+            plan._refresh_amax_for(st)       # (the pooled input buffer may hold a later tensor by now: words to match its bytes)
         st.fn(*st.args, s)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -167,25 +168,13 @@ def conv_event_times(plan, reps=5):
 
 
 def conv_sequence_time(plan, reps=10):
-    """HIP-event time (ms) of ONE pass over the plan's conv launches in forward order, back to back on the launch stream,
-    averaged over `reps` passes: every layer finds its input where the previous launch left it and its weights as cold as a
-    forward leaves them - the state the kernels run in inside the serial graph (the per-layer figure of conv_event_times, five
-    repeats of one launch on hot operands, reads ~10 % lower than the rocprofv3 kernel trace of the forward; this one agrees
-    with it).  Launch boundaries between the conv kernels are inside the interval, as they are inside a forward."""
-    from two_stage_object_detection_amd._ffi import stream_ptr
-    s = stream_ptr()
-    for st in plan.conv_steps:
-        st.fn(*st.args, s)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        for st in plan.conv_steps:
-            st.fn(*st.args, s)
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    plan.clear_range_flag()      # (see conv_event_times)
-    return ms
+    """HIP-event time (ms) of ONE pass over the plan's matrix launches (convs and one-launch bottlenecks) in forward order, back
+    to back on the launch stream, averaged over `reps` passes: every layer finds its input where the previous launch left it and
+    its weights as cold as a forward leaves them - the state the kernels run in inside the serial graph (the per-layer figure of
+    conv_event_times, five repeats of one launch on hot operands, reads ~10 % lower than the rocprofv3 kernel trace of the
+    forward; this one agrees with it).  Launch boundaries between the kernels are inside the interval, as they are inside a
+    forward.  (engine.Plan.sequence_time: FasterRCNN.tune uses the same figure to choose the launch structure.)"""
+    return plan.sequence_time(reps)
 
 
 def conv_in_sequence_times(plan, reps=7):
@@ -195,11 +184,11 @@ def conv_in_sequence_times(plan, reps=7):
     the HBM-bound layer1 launches, whose input then comes from HBM instead of being written just before)."""
     from two_stage_object_detection_amd._ffi import stream_ptr
     s = stream_ptr()
-    n = len(plan.conv_steps)
+    n = len(plan.gemm_steps)
     samples = [[] for _ in range(n)]
     for r in range(reps + 1):
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-        for (e0, e1), st in zip(ev, plan.conv_steps):
+        for (e0, e1), st in zip(ev, plan.gemm_steps):
             e0.record()
             st.fn(*st.args, s)
             e1.record()
@@ -234,7 +223,10 @@ def cpu_baseline(sd, backbone, x_cpu, reps):
 
 
 def step_algorithmic_bytes(st):
-    """Input + output + weights (+ residual, + second source) of one conv launch, each counted once (f32)."""
+    """Input + output + weights (+ residual, + second source) of one conv launch, each counted once (f32); a one-launch
+    bottleneck: its input, its output and its three weight matrices (the intermediates never exist in memory)."""
+    if hasattr(st, "algorithmic_bytes"):
+        return st.algorithmic_bytes
     d = st.desc
     cin = sum(d.seg_len[i] for i in range(d.n_seg))
     tot = 4 * (d.N * d.H * d.W * cin + d.N * d.OH * d.OW * d.Cout + d.Cout * d.KH * d.KW * cin)
@@ -246,24 +238,30 @@ def step_algorithmic_bytes(st):
 
 
 def conv_algorithmic_bytes(plan):
-    return sum(step_algorithmic_bytes(st) for st in plan.conv_steps)
+    return sum(step_algorithmic_bytes(st) for st in plan.gemm_steps)
 
 
 def dump_layers(plan, path, conv_ms=None, seq_ms=None):
-    """Per conv launch of the plan, in launch order: what scripts/summarize_pmc.py needs to put names, algorithmic bytes and
+    """Per matrix launch of the plan, in launch order: what scripts/summarize_pmc.py needs to put names, algorithmic bytes and
     K-slice slab bytes beside the per-dispatch counters."""
     from ctypes import byref
     from two_stage_object_detection_amd._ffi import TILE_NAMES, lib
+    from two_stage_object_detection_amd.engine import FusedStep
     rows = []
-    for i, st in enumerate(plan.conv_steps):
+    for i, st in enumerate(plan.gemm_steps):
         d = st.desc
+        times = {"seq_us": None if seq_ms is None else round(seq_ms[i] * 1e3, 2),          # inside the sequence (the one to quote)
+                 "event_us": None if conv_ms is None else round(conv_ms[i] * 1e3, 2)}      # isolated repeats on hot operands
+        if isinstance(st, FusedStep):
+            rows.append({"name": st.name, "flops": int(st.flops), "algorithmic_bytes": int(st.algorithmic_bytes), "tile": "bottleneck10x16",
+                         "split_k": 1, "precision": 2, "slab_bytes": 0, "M": int(d.N * d.H * d.W), "Cout": int(d.Cout),
+                         "K": int(d.Cin + 9 * d.Cmid + d.Cmid), **times})
+            continue
         ws = int(lib().tsod_conv2d_workspace_bytes(byref(d)))
         rows.append({"name": st.name, "flops": int(st.flops), "algorithmic_bytes": int(step_algorithmic_bytes(st)),
                      "tile": TILE_NAMES[int(d.tile)], "split_k": int(d.split_k), "precision": int(d.precision),
                      "slab_bytes": max(0, ws - 256 * 1024) if ws else 0, "M": int(d.N * d.OH * d.OW), "Cout": int(d.Cout),
-                     "K": int(d.KH * d.KW * sum(d.seg_len[j] for j in range(d.n_seg)) + max(0, int(d.c2))),
-                     "seq_us": None if seq_ms is None else round(seq_ms[i] * 1e3, 2),      # inside the conv sequence (the one to quote)
-                     "event_us": None if conv_ms is None else round(conv_ms[i] * 1e3, 2)})   # isolated repeats on hot operands
+                     "K": int(d.KH * d.KW * sum(d.seg_len[j] for j in range(d.n_seg)) + max(0, int(d.c2))), **times})
     json.dump(rows, open(path, "w"), indent=0)
 
 
@@ -276,14 +274,17 @@ def pmc_child(args, dev):
     model = model.to(dev).eval()
     x = torch.rand(args.batch, 3, args.height, args.width, generator=torch.Generator().manual_seed(1234)).to(dev)
     with torch.inference_mode():
+        table = json.load(open(args.tiles_file)) if args.tiles_file and os.path.exists(args.tiles_file) else None
+        if table is not None:
+            model.extractor.set_fuse_bottleneck(bool(table.get("fuse_bottleneck", False)))
         plan = model.extractor._plan_for(x)                 # packs weights, launches no conv
-        if args.tiles_file and os.path.exists(args.tiles_file):
-            plan.import_tiles(json.load(open(args.tiles_file))["serial"])
+        if table is not None:
+            plan.import_tiles(table["serial"])
         torch.cuda.synchronize()
         L, s = lib(), stream_ptr()
         model(x)                                            # a real forward: warms caches / code objects and leaves this input's
         torch.cuda.synchronize()                            # activations and range words behind (the fp16x2 scales of the sample)
-        for st in plan.conv_steps:                          # the sample: one pass over the conv launches
+        for st in plan.gemm_steps:                          # the sample: one pass over the matrix launches
             st.fn(*st.args, s)
         torch.cuda.synchronize()
 
@@ -303,7 +304,7 @@ def pmc_traffic(args, tiles, n_launches):
     work = tempfile.mkdtemp(prefix="tsod_pmc_", dir="/tmp")
     try:
         tiles_path = os.path.join(work, "tiles.json")
-        json.dump({"serial": tiles}, open(tiles_path, "w"))
+        json.dump({"serial": tiles["serial"], "fuse_bottleneck": bool(tiles.get("fuse_bottleneck", False))}, open(tiles_path, "w"))
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             env.pop(k, None)
@@ -321,7 +322,7 @@ def pmc_traffic(args, tiles, n_launches):
             rows = [(int(q["Dispatch_Id"]), float(q["Counter_Value"])) for q in csv.DictReader(open(files[0]))
                     if q["Counter_Name"] == counter and ("conv_igemm_kernel" in q["Kernel_Name"]
                                                          or "conv_dma_kernel" in q["Kernel_Name"]
-                                                         or "conv_reduce_kernel" in q["Kernel_Name"])]
+                                                         or "bottleneck_kernel" in q["Kernel_Name"])]
             rows.sort()
             if len(rows) < 2 * n_launches:
                 return None, f"unexpected dispatch count {len(rows)} in the {counter} pass"
@@ -527,6 +528,16 @@ def main(argv=None):
         model(x)                                                       # builds the plan
         torch.cuda.synchronize()
         plan = model.extractor._plan_for(x)                           # (the measurement legs below time its launches)
+        from two_stage_object_detection_amd.engine import step_precision
+
+        def use_table(key):
+            """The extractor's plan for x with table `key` pinned.  The serial / in-flight tables may belong to the launch structure
+            with one-launch bottlenecks (tiles["fuse_bottleneck"]); the f32 / bf16x3 comparison legs never do."""
+            model.extractor.set_fuse_bottleneck(bool(tiles.get("fuse_bottleneck", False)) and key in ("serial", "in_flight"))
+            model(x)
+            pl = model.extractor._plan_for(x)
+            pl.import_tiles(tiles[key])
+            return pl
         default_tiles = plan.export_tiles()
         tiles = {"serial": default_tiles, "in_flight": default_tiles}
         splits = [int(v) for v in args.autotune_splits.split(",")] if args.autotune_splits else None
@@ -590,12 +601,13 @@ def main(argv=None):
         f32_leg = None
         if world == 1 and not args.no_autotune and not args.no_graph and args.precision != "f32" and not (tiles_loaded and "f32" not in tiles):
             if "f32" not in tiles:
-                tiles["f32"] = model.tune(x, precisions=(0,), schedules=("serial",), splits=splits, in_sequence=0, heads=False)["serial"]
+                tiles["f32"] = model.tune(x, precisions=(0,), schedules=("serial",), splits=splits, in_sequence=0, heads=False,
+                                          fuse_bottleneck=False)["serial"]
                 if args.tiles_file and rank == 0:
                     json.dump(tiles, open(args.tiles_file, "w"))
-            plan.import_tiles(tiles["f32"])
+            plan = use_table("f32")
             ms32 = conv_sequence_time(plan)
-            fl32 = sum(st.flops for st in plan.conv_steps)
+            fl32 = sum(st.flops for st in plan.gemm_steps)
             f32_leg = {"bound": "mfma", "achieved": round(fl32 / (ms32 * 1e-3) / 1e12, 3), "peak": F32_MFMA_PEAK_TFLOPS,
                        "unit": "TFLOP/s", "frac": round(fl32 / (ms32 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                        "kernel_ms_per_forward": round(ms32, 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
@@ -606,31 +618,32 @@ def main(argv=None):
         if world == 1 and not args.no_autotune and not args.no_graph and 2 in precs and not (tiles_loaded and "bf16x3" not in tiles):
             if "bf16x3" not in tiles:
                 tiles["bf16x3"] = model.tune(x, precisions=(0, 1), schedules=("serial",), splits=splits,
-                                             in_sequence=args.autotune_in_sequence, heads=False)["serial"]
+                                             in_sequence=args.autotune_in_sequence, heads=False, fuse_bottleneck=False)["serial"]
                 if args.tiles_file and rank == 0:
                     json.dump(tiles, open(args.tiles_file, "w"))
-            plan.import_tiles(tiles["bf16x3"])
+            plan = use_table("bf16x3")
             msb = conv_sequence_time(plan)
-            flb = sum(st.flops for st in plan.conv_steps)
-            prb = [int(st.desc.precision) for st in plan.conv_steps]
-            idb = sum(st.flops / ((BF16X3_PEAK_TFLOPS if pr == 1 else F32_MFMA_PEAK_TFLOPS) * 1e12) * 1e3 for st, pr in zip(plan.conv_steps, prb))
+            flb = sum(st.flops for st in plan.gemm_steps)
+            prb = [step_precision(st) for st in plan.gemm_steps]
+            idb = sum(st.flops / ((BF16X3_PEAK_TFLOPS if pr == 1 else F32_MFMA_PEAK_TFLOPS) * 1e12) * 1e3 for st, pr in zip(plan.gemm_steps, prb))
             bf_leg = {"bound": "mfma", "achieved": round(flb / (msb * 1e-3) / 1e12, 3), "peak": round(flb / (idb * 1e-3) / 1e12, 1),
                       "unit": "TFLOP/s", "frac": round(idb / msb, 4), "kernel_ms_per_forward": round(msb, 4),
                       "dtype": "bf16x3 / f32 MFMA per layer (no fp16x2)",
                       "note": "the same conv launches with a tile table tuned among f32 and bf16x3 only (one pass in forward order, HIP "
                               "events): the arithmetic of rounds 2-3, not the timed path when fp16x2 is among the candidates"}
         # ---- schedule 1: strictly serial (one graph, one stream) + the per-kernel roofline that belongs to it
-        plan.import_tiles(tiles["serial"])
+        plan = use_table("serial")
         conv_ms = conv_event_times(plan)
         conv_seq_ms = conv_sequence_time(plan)
         if args.dump_layers and rank == 0:
             dump_layers(plan, args.dump_layers, conv_ms, conv_in_sequence_times(plan))
-        conv_flops = sum(st.flops for st in plan.conv_steps)
+        conv_flops = sum(st.flops for st in plan.gemm_steps)
         algo_bytes = conv_algorithmic_bytes(plan)
-        precs = [int(st.desc.precision) for st in plan.conv_steps]
-        flops_bf = sum(st.flops * (6 if pr == 1 else 3) for st, pr in zip(plan.conv_steps, precs) if pr >= 1) / 6.0
+        precs = [step_precision(st) for st in plan.gemm_steps]
+        n_fused = len(plan.fused_steps)
+        flops_bf = sum(st.flops * (6 if pr == 1 else 3) for st, pr in zip(plan.gemm_steps, precs) if pr >= 1) / 6.0
         peak_of = {0: F32_MFMA_PEAK_TFLOPS, 1: BF16X3_PEAK_TFLOPS, 2: FP16X2_PEAK_TFLOPS}
-        ideal_ms = sum(st.flops / (peak_of[pr] * 1e12) * 1e3 for st, pr in zip(plan.conv_steps, precs))
+        ideal_ms = sum(st.flops / (peak_of[pr] * 1e12) * 1e3 for st, pr in zip(plan.gemm_steps, precs))
         if args.no_graph:
             n_fly = 1
 
@@ -695,7 +708,7 @@ def main(argv=None):
         eff_peak = conv_flops / (ideal_ms * 1e-3) / 1e12               # FLOP-weighted harmonic peak of the layers' arithmetics
         n_bf = sum(1 for pr in precs if pr == 1)
         n_h2 = sum(1 for pr in precs if pr == 2)
-        traffic, traffic_note = (None, "skipped") if (n_gpus > 1 or args.no_pmc) else pmc_traffic(args, tiles["serial"], len(conv_ms))
+        traffic, traffic_note = (None, "skipped") if (n_gpus > 1 or args.no_pmc) else pmc_traffic(args, tiles, len(conv_ms))
         step_flops = conv_flops                                           # conv GEMM FLOPs of one step (B images)
         line = {
             "metric": "images/sec Faster R-CNN ResNet-50 @800x1333" if args.backbone == "resnet50"
@@ -740,7 +753,9 @@ def main(argv=None):
                                          + ("" if traffic_note is None else f" [{traffic_note}]"),
                          "algorithmic_bytes_per_launch": round(algo_bytes / len(conv_ms)),
                          "traffic_over_algorithmic": None if traffic is None else round(traffic * len(conv_ms) / algo_bytes, 3),
-                         "kernel": f"conv_igemm_kernel / conv_dma_kernel (implicit GEMM; per layer f32 MFMA, bf16x3 MFMA register-staged, or bf16x3 MFMA fed by LDS-DMA), {len(conv_ms)} launches per forward",
+                         "kernel": f"conv_igemm_kernel / conv_dma_kernel (implicit GEMM; per layer f32 MFMA, bf16x3 or fp16x2 MFMA, register-staged or "
+                                   f"fed by LDS-DMA)" + (f" + bottleneck_kernel ({n_fused} identity bottlenecks of layer1 as one launch each)" if n_fused else "")
+                                   + f", {len(conv_ms)} launches per forward",
                          "schedule": "serial", "flops_per_forward": conv_flops,
                          "kernel_ms_per_forward": round(conv_total_ms, 4),
                          "kernel_ms_measured_as": "HIP events around one pass over the conv launches in forward order (cache state of a "

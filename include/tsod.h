@@ -201,6 +201,37 @@ int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, const float
                          const float *scale, const float *shift, const float *residual, float *out,
                          void *workspace, size_t workspace_bytes, tsod_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * A whole identity-shortcut ResNet bottleneck in ONE launch (models/resnet.py:57-76 with stride 1 and downsample None: the
+ * blocks 1.. of `layer1 = _make_layer(64, 3)`, :99):
+ *     out = PReLU(BN3(conv1x1(PReLU(BN2(conv3x3(PReLU(BN1(conv1x1(x)))))))) + x)        Cin -> 64 -> 64 -> Cout, Cout == Cin
+ * The two 64-channel intermediates never leave the CU (LDS), so the block moves x (+ a one-pixel halo), x again for the
+ * residual (an L2 / Infinity-Cache hit) and out, instead of 273 MB per image at 3x800x1333 in three launches.  FP16X2
+ * arithmetic (see TSOD_PREC_FP16X2): x is split with the scale of amax_in (or the static a_scale_exp), the intermediates with
+ * the scale of each tile's own abs-max.  This build: Cmid == 64, Cin == Cout, both multiples of 64.
+ *
+ * `wstream`: the three convs' weights as ONE stream of 8 KB steps in consumption order - Cin/32 steps of conv1 (k = 32 s ..),
+ * 18 of conv2 (step = (tap kh*3+kw, channel half)), 2 per 64 output channels of conv3 - each step the LDS image of
+ * [64 rows][32 k] fp16 of 2^w_exp[i] * w as two planes (hi at +0, lo at +4096; lo = rne(2^e w - hi)): row r = 32 cb + i holds
+ * output channel base + 32 cb + pi(i), pi(i) = 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3); a row is 4 slots of 8 k, slot s stored
+ * at slot s ^ ((r >> 2) & 3) (bank swizzle).  `bn`: f32 [s1(64) | b1(64) | s2(64) | b2(64) | s3(Cout) | b3(Cout)], the folded
+ * BatchNorm scale / shift of the three convs.  No workspace. */
+typedef struct tsod_bottleneck_desc {
+    int32_t N, H, W;              /* images, height, width (input and output) */
+    int32_t Cin, in_pitch;        /* x: [N][H][W][in_pitch], channels [0, Cin) */
+    int32_t Cmid;                 /* 64 */
+    int32_t Cout, out_pitch;      /* out: [N][H][W][out_pitch] */
+    float slope;                  /* the block's one PReLU slope */
+    int32_t w_exp[3];             /* exponents the three convs' weights were scaled with in wstream */
+    int32_t a_scale_exp;          /* static exponent for x when amax_in == NULL */
+    int32_t *range_flag;          /* optional, as in tsod_conv2d_desc */
+    const uint32_t *amax_in;      /* optional range words of x */
+    uint32_t *amax_out;           /* optional range words of out */
+} tsod_bottleneck_desc;
+size_t tsod_bottleneck_wstream_bytes(int32_t Cin, int32_t Cout);
+int tsod_bottleneck_fp16x2(const tsod_bottleneck_desc *d, const float *x, const void *wstream, const float *bn, float *out,
+                           tsod_stream_t stream);
+
 /* nn.Linear (nets/classify.py:13,15): out[M,N] = in[M,K] @ w[N,K]^T + bias.  K % 4 == 0. */
 int tsod_linear_f32(const float *in, int32_t M, int32_t K, int32_t in_pitch, const float *w /* [N][K] */,
                     const float *bias /* [N] or NULL */, int32_t N, float *out, int32_t out_pitch,

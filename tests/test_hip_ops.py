@@ -904,3 +904,64 @@ def test_conv_fp16x2_scale_follows_the_tensor(ops, dev, scale):
         flag.zero_()
         ops.conv2d_nhwc(xbad, wp, pad=1, tile=tile, split_k=1, precision=2, amax_in=wbad, range_flag=flag)
         assert int(flag.item()) == 1, tile
+
+
+def _bottleneck_reference(x, w1, w2, w3, bn, slope):
+    """f64 CPU: out = PReLU(BN3(conv1x1(PReLU(BN2(conv3x3(PReLU(BN1(conv1x1(x)))))))) + x) (models/resnet.py:57-76, identity shortcut)"""
+    act = lambda t: torch.where(t >= 0, t, slope * t)      # noqa: E731
+    s1, b1, s2, b2, s3, b3 = (v.double().view(1, -1, 1, 1) for v in bn)
+    y = act(F.conv2d(x.double(), w1.double()) * s1 + b1)
+    y = act(F.conv2d(y, w2.double(), padding=1) * s2 + b2)
+    return act(F.conv2d(y, w3.double()) * s3 + b3 + x.double()).float()
+
+
+@pytest.mark.parametrize("N,H,W,C,gain", [(1, 10, 16, 256, 1.0), (2, 23, 37, 256, 1.0), (1, 31, 20, 64, 1.0), (1, 12, 50, 256, 500.0), (1, 9, 9, 128, 1e-4)])
+def test_bottleneck_fused_matches_the_f64_block(ops, dev, N, H, W, C, gain):
+    """tsod_bottleneck_fp16x2: a whole identity bottleneck in one launch (both 64-channel intermediates in LDS) against the f64
+    CPU block - tile edges (H, W not multiples of the 10 x 16 tile; one-tile and multi-tile images), the zero padding of the 3x3
+    (y1 is padded, not x: a border pixel's halo must be exact zeros), the tile-local scales of the intermediates and the range
+    words of x (inputs 500x larger / 10^4 x smaller), and the abs-max it leaves for its consumer."""
+    g = torch.Generator().manual_seed(123 + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    x = torch.maximum(x, 0.25 * x) * gain
+    w1 = torch.randn(64, C, 1, 1, generator=g) / math.sqrt(C)
+    w2 = torch.randn(64, 64, 3, 3, generator=g) / math.sqrt(576)
+    w3 = torch.randn(C, 64, 1, 1, generator=g) / 8.0
+    bn = [torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1 * gain, torch.rand(64, generator=g) + 0.5,
+          torch.randn(64, generator=g) * 0.1 * gain, torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1 * gain]
+    slope = 0.25
+    ref = _bottleneck_reference(x, w1, w2, w3, bn, slope)
+    xn = ops.nchw_to_nhwc(x.to(dev))
+    w2p = ops.pack_conv_weight(w2.to(dev))                              # [64, 3, 3, 64]
+    stream, exps = ops.pack_bottleneck_wstream(w1.view(64, C).to(dev), w2p, w3.view(C, 64).to(dev))
+    bnv = torch.cat(bn).to(dev)
+    words = ops.absmax(xn, ops.new_amax_words(dev, 1))
+    wout = ops.new_amax_words(dev, 1)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    out = ops.bottleneck_fused(xn, stream, exps, bnv, C, slope, amax_in=words, amax_out=wout, range_flag=flag)
+    got = ops.nhwc_to_nchw(out).cpu()
+    tol = (3e-6 * math.sqrt(576) + 1e-5) * float(ref.abs().max()) / 4.0 + 1e-6 * gain
+    err = (got - ref).abs().max().item()
+    assert err <= tol, (err, tol)
+    assert int(flag.item()) == 0
+    assert ops.amax_value(wout) == float(out.abs().max())
+    # the same block as three launches of the conv kernel (fp16x2, f32 intermediates in HBM): same arithmetic, other summation order
+    sc = lambda v: v.to(dev)      # noqa: E731
+    y1 = ops.conv2d_nhwc(xn, ops.pack_conv_weight(w1.to(dev)), scale=sc(bn[0]), shift=sc(bn[1]), act=1, slope=slope, precision=2, amax_in=words)
+    w_y1 = ops.absmax(y1, ops.new_amax_words(dev, 1))
+    y2 = ops.conv2d_nhwc(y1, w2p, pad=1, scale=sc(bn[2]), shift=sc(bn[3]), act=1, slope=slope, precision=2, amax_in=w_y1)
+    w_y2 = ops.absmax(y2, ops.new_amax_words(dev, 1))
+    o3 = ops.conv2d_nhwc(y2, ops.pack_conv_weight(w3.to(dev)), scale=sc(bn[4]), shift=sc(bn[5]), residual=xn, act=1, slope=slope, precision=2,
+                         amax_in=w_y2)
+    assert (ops.nhwc_to_nchw(o3).cpu() - got).abs().max().item() <= tol
+    if gain == 1.0 and C == 256:
+        # static exponent path (no range words) and the refusals
+        out2 = ops.bottleneck_fused(xn, stream, exps, bnv, C, slope, a_scale_exp=8)
+        assert (ops.nhwc_to_nchw(out2).cpu() - ref).abs().max().item() <= tol
+        xbad = xn.clone()
+        xbad[0, 2, 3, 5] = float("nan")
+        ops.bottleneck_fused(xbad, stream, exps, bnv, C, slope, a_scale_exp=8, range_flag=flag)
+        assert int(flag.item()) == 1
+        from two_stage_object_detection_amd._ffi import TsodError
+        with pytest.raises(TsodError):                                 # channel counts must be multiples of 64
+            ops.bottleneck_fused(xn, stream, exps, bnv, 96, slope)

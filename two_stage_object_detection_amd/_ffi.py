@@ -50,6 +50,15 @@ class ConvDesc(Structure):
     ]
 
 
+class BottleneckDesc(Structure):
+    """Mirror of ``tsod_bottleneck_desc`` (include/tsod.h)."""
+    _fields_ = [
+        ("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("in_pitch", c_int32), ("Cmid", c_int32),
+        ("Cout", c_int32), ("out_pitch", c_int32), ("slope", c_float), ("w_exp", c_int32 * 3), ("a_scale_exp", c_int32),
+        ("range_flag", c_void_p), ("amax_in", c_void_p), ("amax_out", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/tsod.h declares
 _SIGNATURES = {
     "tsod_status_str": (c_char_p, [c_int]),
@@ -66,6 +75,8 @@ _SIGNATURES = {
                                 c_void_p, c_size_t, c_void_p]),
     "tsod_conv2d_dual_f32": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
+    "tsod_bottleneck_wstream_bytes": (c_size_t, [c_int32, c_int32]),
+    "tsod_bottleneck_fp16x2": (c_int, [POINTER(BottleneckDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tsod_linear_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32,
                                 c_void_p, c_size_t, c_void_p]),
     "tsod_linear_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

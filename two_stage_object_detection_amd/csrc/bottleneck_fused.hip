@@ -1,0 +1,458 @@
+// bottleneck_fused.hip -- a whole ResNet bottleneck (models/resnet.py:57-76, stride 1, identity shortcut) in ONE launch:
+//
+//     y1  = PReLU(BN1(conv1x1(x)))          Cin  -> 64      on the tile's pixels + a one-pixel halo
+//     y2  = PReLU(BN2(conv3x3(y1)))         64   -> 64      from LDS (y1 never leaves the CU)
+//     out = PReLU(BN3(conv1x1(y2)) + x)     64   -> Cout    (Cout == Cin: the identity blocks of layer1)
+//
+// Why: the three launches of such a block move 273 MB per image at 3x800x1333 (x read by conv1, y1 written and read, y2 written
+// and read, x read again as the residual, out written) for 3.6 GFLOP - layer1 is the one HBM-bound stage of the trunk
+// (profiles/r03_b8_pmc_summary.md rows 4-9: 5.5 TB/s).  Here y1 and y2 live in LDS: x (+ halo) in, x again (residual: an L2 / Infinity
+// Cache hit, the same workgroup read it a few microseconds earlier), out out.
+//
+// Arithmetic: "fp16x2" as in conv_igemm_f32.hip (two fp16 pieces per operand, three products on v_mfma_f32_32x32x16_f16, f32
+// accumulation): x is split with the scale its range words give (or the static exponent), y1 and y2 with the scale THIS TILE's own
+// abs-max calls for (a workgroup-wide max through LDS: a GEMM only needs one scale per accumulation, and every accumulation here
+// is over values of one tile) - no range words for tensors that never exist.
+//
+// Layout of a workgroup (256 threads = 4 waves), output tile TH x TW = 10 x 16 pixels (160 = 5 blocks of 32), halo 12 x 18 =
+// 216 -> 224 rows (7 blocks):
+//   * MFMA orientation: first operand = WEIGHTS (32 output channels), second = ACTIVATIONS (32 pixels): an accumulator lane then
+//     holds 16 values of ONE pixel, and with the weight rows permuted (pi below) they are 16 CONSECUTIVE channels: 64 contiguous
+//     bytes per lane for the residual loads and output stores, two ds_write_b128 per plane for y1 / y2.
+//   * weights: ALL three convs as one stream of 8 KB steps (64 output channels x 32 k x (hi, lo)), pre-packed by the host in
+//     consumption order and in the exact LDS image (row permutation and bank swizzle included): the loader is a plain copy through
+//     a two-slot ring.  Cin = 256: 8 + 18 + 8 = 34 steps.
+//   * conv1's activations: the x halo tile, one 32-channel K-step at a time through LDS (split into pieces on the way in);
+//     conv2's: y1 planes in LDS, the im2col gather is the fragment's row address; conv3's: y2 planes (the y1 region re-used).
+//   * a wave owns one 32-channel block of the step's 64 and every second pixel block: ONE weight fragment pair per 16-k chunk
+//     feeds up to four activation fragments.
+#include "tsod_internal.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TH = 10, TW = 16, HW_ = TW + 2, HALO = (TH + 2) * (TW + 2);   // 216 halo pixels
+constexpr int CMID = 64;
+// y planes: [224 rows][64 channels] fp16 at a pitch of 144 bytes (9 x 16: the 16 rows of a ds_read_b128 lane group land in 16 distinct
+// 16-byte bank groups without an XOR, so a fragment address is ONE per-lane base + an immediate offset - tap shift, channel slot and
+// plane are all compile-time in the unrolled loops)
+constexpr int Y_PITCH = 144, Y_PLANE = 224 * Y_PITCH;
+constexpr int A_PLANE = 224 * 64;                // one fp16 plane of conv1's x stage: [224 rows][32 k], XOR-swizzled (inside the y region)
+constexpr int Y_BYTES = 2 * Y_PLANE;             // 64 512
+constexpr int W_STEP = 8192;                     // one weight step: [64 rows][32 k] x (hi, lo)
+constexpr int W_OFF = Y_BYTES, SCR_OFF = W_OFF + 2 * W_STEP, LDS_BYTES = SCR_OFF + 64;
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+constexpr unsigned kOOB = 0xFFFFFFF0u;           // byte offset beyond any buffer-descriptor extent: loads return 0, stores are dropped
+
+struct Params {
+    const float *x;            // [N][H][W][in_pitch]
+    float *out;                // [N][H][W][out_pitch]
+    const unsigned char *wstream;
+    const float *bn;           // [s1(64) | b1(64) | s2(64) | b2(64) | s3(Cout) | b3(Cout)]
+    int N, H, W, Cin, in_pitch, Cout, out_pitch;
+    int tiles_x, tiles_y;
+    unsigned x_bytes, out_bytes;
+    float slope;
+    int w_exp1, w_exp2, w_exp3;
+    float a_scale;             // static 2^a_scale_exp (no range words)
+    const unsigned *amax_in;
+    unsigned *amax_out;
+    int *range_flag;
+    int dbg;                   // timing experiments only (TSOD_BN_DBG): 1 no x loads after the first, 2 no residual loads, 4 no weight loads after
+                               // the first two steps, 8 no output stores - wrong results by design, never set by the library's callers
+};
+
+__device__ __forceinline__ float prelu(float v, float a) { return fmaxf(v, 0.f) + a * fminf(v, 0.f); }
+
+// two fp16 pieces of s * x for a pair of elements (the same bits as split2_pair of conv_igemm_f32.hip)
+__device__ __forceinline__ void split2(float x0, float x1, float sc, unsigned &h, unsigned &l) {
+    const float a0 = sc * x0, a1 = sc * x1;
+    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+    const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+    h = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    l = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+}
+
+// three piece products, smallest first: lo*hi, hi*lo, hi*hi
+__device__ __forceinline__ void mfma3(f32x16 &acc, const u32x4 &wh, const u32x4 &wl, const u32x4 &ah, const u32x4 &al) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wl), __builtin_bit_cast(f16x8, ah), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, al), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, ah), acc, 0, 0, 0);
+}
+
+// byte offset of 16-byte slot `slot` of row `row` in the XOR-swizzled 64-byte-row tiles (x stage, weight steps: 4 slots per row, 4 rows
+// per 256-byte bank line)
+__device__ __forceinline__ int off64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+// workgroup-wide max of a non-negative value through LDS (two barriers); every thread gets it
+__device__ __forceinline__ float block_max(float v, float *scr, int tid) {
+    v = tsod_wave_max(v);
+    __syncthreads();
+    if ((tid & 63) == 0) scr[tid >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(scr[0], scr[1]), fmaxf(scr[2], scr[3]));
+}
+
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+__global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
+    __shared__ __align__(16) unsigned char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;             // fragment column (pixel) / row (weight row) index, k half
+    const int cb = wave & 1, pb0 = wave >> 1;            // this wave's channel block of the step's 64, its first pixel block (stride 2)
+    const int nb1 = pb0 == 0 ? 4 : 3, nb2 = pb0 == 0 ? 3 : 2;   // pixel blocks this wave owns: of the halo's 7, of the tile's 5
+    float *scr = reinterpret_cast<float *>(lds + SCR_OFF);
+
+    // ---- the tile
+    // blocks b, b + 8, ... share an XCD (private L2; observed round-robin placement - a speed matter only): XCD x takes a contiguous
+    // run of the tile order, so that neighbouring tiles - which share halo pixels - are read through ONE L2
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int nwg = (int)gridDim.x, per = nwg >> 3, r8 = nwg & 7, xcd = (int)blockIdx.x & 7;
+    const int tile_id = (xcd < r8 ? xcd * (per + 1) : r8 * (per + 1) + (xcd - r8) * per) + ((int)blockIdx.x >> 3);
+    const int img = tile_id / tiles_per_img, t_in = tile_id - img * tiles_per_img;
+    const int ty = t_in / p.tiles_x, tx = t_in - ty * p.tiles_x;
+    const int h0 = ty * TH, w0 = tx * TW;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, (short)0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, (short)0, (int)((p.dbg & 8) ? 0u : p.out_bytes), 0x00020000);
+
+    // ---- x scale: the static exponent, or what the input's range words call for (wave-uniform)
+    float a_scale = p.a_scale;
+    int e_x;
+    if (p.amax_in != nullptr) {
+        e_x = tsod_fp16x2_exp_from_bits(tsod_amax_reduce_bits(p.amax_in[lane * TSOD_AMAX_STRIDE_WORDS]));
+        a_scale = __uint_as_float((unsigned)(127 + e_x) << 23);
+    } else {
+        e_x = (int)(__float_as_uint(a_scale) >> 23) - 127;
+    }
+    a_scale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(a_scale)));
+
+    // ---- weight stream: step s = 8 KB, thread t copies 16-byte units t and t + 256 into ring slot (s & 1)
+    const int n_steps1 = p.Cin / 32, n_steps = n_steps1 + 18 + (p.Cout / 64) * 2;
+    u32x4 wr0, wr1;
+    auto w_load = [&](int s) {
+        if ((p.dbg & 4) && s > 1) return;
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(p.wstream + (size_t)s * W_STEP);
+        wr0 = src[tid];
+        wr1 = src[tid + 256];
+    };
+    auto w_store = [&](int slot) {
+        u32x4 *dst = reinterpret_cast<u32x4 *>(lds + W_OFF + slot * W_STEP);
+        dst[tid] = wr0;
+        dst[tid + 256] = wr1;
+    };
+    // weight fragments of this wave's channel block: row cb * 32 + j, chunk c = slots 2 c + hh (XOR-swizzled): two per-lane addresses;
+    // ring slot and plane are immediate offsets
+    const unsigned char *wfa[2] = {lds + W_OFF + off64(cb * 32 + j, hh), lds + W_OFF + off64(cb * 32 + j, 2 + hh)};
+    auto w_frag = [&](int slot, int c, u32x4 &wh, u32x4 &wl) {
+        wh = *reinterpret_cast<const u32x4 *>(wfa[c] + slot * W_STEP);
+        wl = *reinterpret_cast<const u32x4 *>(wfa[c] + slot * W_STEP + W_STEP / 2);
+    };
+
+    // ---- conv1's x stage: 224 rows x 8 float4 per K-step = 7 float4 per thread; unit u = tid + 256 i: row = u >> 3, quad = u & 7
+    unsigned xoff[7];                                  // byte offset of the unit in x at K-step 0 (kOOB: outside the image / padding row)
+    int xdst[7];                                       // byte offset of the unit's 8 bytes inside an x-stage plane
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int u = tid + 256 * i, row = u >> 3, q = u & 7;
+        const int hr = row / HW_, hc = row - hr * HW_;
+        const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
+        const bool ok = row < HALO && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+        xoff[i] = ok ? (unsigned)((((long)img * p.H + gh) * p.W + gw) * p.in_pitch + q * 4) * 4u : kOOB;
+        xdst[i] = off64(row, q >> 1) + (q & 1) * 8;
+    }
+    float4 xr[7];
+    auto x_load = [&](int ks) {
+        if ((p.dbg & 1) && ks > 0) return;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) xr[i] = bload4(rs_x, xoff[i] != kOOB ? xoff[i] + (unsigned)ks * 128u : kOOB);
+    };
+    auto x_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            unsigned h0_, l0_, h1_, l1_;
+            split2(xr[i].x, xr[i].y, a_scale, h0_, l0_);
+            split2(xr[i].z, xr[i].w, a_scale, h1_, l1_);
+            *reinterpret_cast<uint2 *>(lds + xdst[i]) = make_uint2(h0_, h1_);
+            *reinterpret_cast<uint2 *>(lds + A_PLANE + xdst[i]) = make_uint2(l0_, l1_);
+        }
+    };
+    // x fragments of the wave's pixel blocks: row (pb0 + 2 b) * 32 + j, chunk c
+    const unsigned char *xfa[4][2];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) xfa[b][c] = lds + off64((pb0 + 2 * b) * 32 + j, 2 * c + hh);
+
+    // ================= conv1: y1[224 x 64] = x_halo[224 x Cin] . W1^T =================
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+    w_load(0);
+    x_load(0);
+    w_store(0);
+    x_store();
+    __syncthreads();
+    // one step: weights from ring slot SLOT (compile-time), x stage -> MFMAs; behind it the next step's operands go into LDS
+    auto conv1_step = [&](auto SLOT, int ks) {
+        constexpr int slot = decltype(SLOT)::value;
+        w_load(ks + 1);                                  // (conv2's first step behind conv1's last)
+        if (ks + 1 < n_steps1) x_load(ks + 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            u32x4 wh, wl;
+            w_frag(slot, c, wh, wl);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b < nb1) {
+                    const u32x4 ah = *reinterpret_cast<const u32x4 *>(xfa[b][c]);
+                    const u32x4 al = *reinterpret_cast<const u32x4 *>(xfa[b][c] + A_PLANE);
+                    mfma3(acc[b], wh, wl, ah, al);
+                }
+            }
+        }
+        __syncthreads();                                 // every wave is done with the x stage (and with ring slot `slot`'s predecessor)
+        w_store(slot ^ 1);
+        if (ks + 1 < n_steps1) {
+            x_store();
+            __syncthreads();
+        }
+    };
+    for (int ks = 0; ks < n_steps1; ks += 2) {           // (Cin is a multiple of 64: an even number of steps)
+        conv1_step(std::integral_constant<int, 0>{}, ks);
+        conv1_step(std::integral_constant<int, 1>{}, ks + 1);
+    }
+    // ---- y1 = PReLU(BN1(.)), zero outside the image (conv2's zero padding pads y1, not x), tile-wide scale, pieces into LDS
+    // acc[b][e]: pixel row (pb0 + 2 b) * 32 + j of the halo, channel cb * 32 + 16 hh + e
+    const int ch16 = cb * 32 + 16 * hh;
+    const float sc1 = __uint_as_float((unsigned)(127 - e_x - p.w_exp1) << 23);
+    float mx = 0.f, chk = 0.f;
+    {
+        float sv[16], bv[16];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float4 s4 = *reinterpret_cast<const float4 *>(p.bn + ch16 + 4 * v), b4 = *reinterpret_cast<const float4 *>(p.bn + 64 + ch16 + 4 * v);
+            sv[4 * v] = s4.x * sc1; sv[4 * v + 1] = s4.y * sc1; sv[4 * v + 2] = s4.z * sc1; sv[4 * v + 3] = s4.w * sc1;
+            bv[4 * v] = b4.x; bv[4 * v + 1] = b4.y; bv[4 * v + 2] = b4.z; bv[4 * v + 3] = b4.w;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b >= nb1) continue;
+            const int row = (pb0 + 2 * b) * 32 + j, hr = row / HW_, hc = row - hr * HW_;
+            const bool ok = row < HALO && (unsigned)(h0 - 1 + hr) < (unsigned)p.H && (unsigned)(w0 - 1 + hc) < (unsigned)p.W;
+            const float keep = ok ? 1.f : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                chk = fmaf(acc[b][e], 0.f, chk);                 // (NaN once any accumulator is inf / NaN: PReLU's max / min would hide it)
+                const float v = keep * prelu(fmaf(acc[b][e], sv[e], bv[e]), p.slope);
+                acc[b][e] = v;
+                mx = fmaxf(mx, fabsf(v));
+            }
+        }
+    }
+    mx = block_max(mx, scr, tid);                        // (its first barrier also orders the x stage's last reads before the y1 writes)
+    const int e1 = tsod_fp16x2_exp_from_bits(__float_as_uint(mx));
+    const float ys1 = __uint_as_float((unsigned)(127 + e1) << 23);
+    auto y_store = [&](const f32x16 &v, int row, float ysc) {
+        unsigned hq[8], lq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split2(v[2 * e], v[2 * e + 1], ysc, hq[e], lq[e]);
+        unsigned char *dst = lds + row * Y_PITCH + (4 * cb + 2 * hh) * 16;
+        *reinterpret_cast<u32x4 *>(dst) = u32x4{hq[0], hq[1], hq[2], hq[3]};
+        *reinterpret_cast<u32x4 *>(dst + 16) = u32x4{hq[4], hq[5], hq[6], hq[7]};
+        *reinterpret_cast<u32x4 *>(dst + Y_PLANE) = u32x4{lq[0], lq[1], lq[2], lq[3]};
+        *reinterpret_cast<u32x4 *>(dst + Y_PLANE + 16) = u32x4{lq[4], lq[5], lq[6], lq[7]};
+    };
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        if (b < nb1) y_store(acc[b], (pb0 + 2 * b) * 32 + j, ys1);
+    __syncthreads();
+
+    // ================= conv2: y2[160 x 64] = im2col(y1)[160 x 576] . W2^T (18 steps: tap, channel half) =================
+    // this lane's output pixels (one per owned pixel block): the address of its halo row at tap (0, 0), k half included
+    const unsigned char *yfa[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        int pidx = (pb0 + 2 * b) * 32 + j;
+        pidx = pidx < TH * TW ? pidx : TH * TW - 1;      // (rows of a block past the tile compute a duplicate, never stored)
+        yfa[b] = lds + ((pidx / TW) * HW_ + (pidx % TW)) * Y_PITCH + hh * 16;
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+    const int s2base = n_steps1;                          // (even: conv2's step t sits in ring slot t & 1)
+#pragma unroll
+    for (int t = 0; t < 18; ++t) {
+        w_load(s2base + t + 1);
+        const int tap = t >> 1, kh = tap / 3, kw = tap - kh * 3;
+        const int imm = (kh * HW_ + kw) * Y_PITCH + (t & 1) * 64;      // tap shift + channel half: an immediate after unrolling
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            u32x4 wh, wl;
+            w_frag(t & 1, c, wh, wl);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                if (b < nb2) {
+                    const u32x4 ah = *reinterpret_cast<const u32x4 *>(yfa[b] + imm + c * 32);
+                    const u32x4 al = *reinterpret_cast<const u32x4 *>(yfa[b] + imm + c * 32 + Y_PLANE);
+                    mfma3(acc[b], wh, wl, ah, al);
+                }
+            }
+        }
+        w_store((t & 1) ^ 1);                            // that slot was last read in step t - 1: a barrier ago
+        __syncthreads();
+    }
+    // ---- y2 = PReLU(BN2(.)) -> pieces into the y region (y1 is dead: every wave is past the last step's barrier)
+    const float sc2 = __uint_as_float((unsigned)(127 - e1 - p.w_exp2) << 23);
+    mx = 0.f;
+    {
+        float sv[16], bv[16];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float4 s4 = *reinterpret_cast<const float4 *>(p.bn + 128 + ch16 + 4 * v), b4 = *reinterpret_cast<const float4 *>(p.bn + 192 + ch16 + 4 * v);
+            sv[4 * v] = s4.x * sc2; sv[4 * v + 1] = s4.y * sc2; sv[4 * v + 2] = s4.z * sc2; sv[4 * v + 3] = s4.w * sc2;
+            bv[4 * v] = b4.x; bv[4 * v + 1] = b4.y; bv[4 * v + 2] = b4.z; bv[4 * v + 3] = b4.w;
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b >= nb2) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                chk = fmaf(acc[b][e], 0.f, chk);
+                const float v = prelu(fmaf(acc[b][e], sv[e], bv[e]), p.slope);
+                acc[b][e] = v;
+                mx = fmaxf(mx, fabsf(v));
+            }
+        }
+    }
+    mx = block_max(mx, scr, tid);
+    const int e2 = tsod_fp16x2_exp_from_bits(__float_as_uint(mx));
+    const float ys2 = __uint_as_float((unsigned)(127 + e2) << 23);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+        if (b < nb2) y_store(acc[b], (pb0 + 2 * b) * 32 + j, ys2);
+    __syncthreads();
+
+    // ================= conv3: out[160 x Cout] = y2[160 x 64] . W3^T + x, 64 output channels (two weight steps) at a time ======
+    const float sc3 = __uint_as_float((unsigned)(127 - e2 - p.w_exp3) << 23);
+    float amax = 0.f;
+    // this lane's output pixels: byte offsets of the pixel's channel 0 in x and in out, its y2 row
+    unsigned xpix[3], opix[3];
+    const unsigned char *y2a[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int pidx = (pb0 + 2 * b) * 32 + j, pr = pidx / TW, pc = pidx - pr * TW;
+        const bool ok = b < nb2 && pidx < TH * TW && h0 + pr < p.H && w0 + pc < p.W;
+        const long gp = ((long)img * p.H + h0 + pr) * p.W + w0 + pc;
+        xpix[b] = ok ? (unsigned)(gp * p.in_pitch) * 4u : kOOB;
+        opix[b] = ok ? (unsigned)(gp * p.out_pitch) * 4u : kOOB;
+        y2a[b] = lds + pidx * Y_PITCH + hh * 16;
+    }
+    const int s3base = n_steps1 + 18;                    // (even)
+    for (int q = 0; q < p.Cout / 64; ++q) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+        const unsigned chb = (unsigned)(q * 64 + ch16) * 4u;            // byte offset of this lane's 16 channels inside a pixel
+        if (s3base + 2 * q + 1 < n_steps) w_load(s3base + 2 * q + 1);    // (the weights first: in-order returns - they are needed first)
+        // the residual of this 64-channel slice: issued before the MFMAs, consumed behind them
+        float4 res[3][4];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) res[b][v] = bload4(rs_x, (xpix[b] != kOOB && !(p.dbg & 2)) ? xpix[b] + chb + 16u * v : kOOB);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 1 && s3base + 2 * q + 2 < n_steps) w_load(s3base + 2 * q + 2);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                u32x4 wh, wl;
+                w_frag(ks, c, wh, wl);
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    if (b < nb2) {
+                        const u32x4 ah = *reinterpret_cast<const u32x4 *>(y2a[b] + ks * 64 + c * 32);
+                        const u32x4 al = *reinterpret_cast<const u32x4 *>(y2a[b] + ks * 64 + c * 32 + Y_PLANE);
+                        mfma3(acc[b], wh, wl, ah, al);
+                    }
+                }
+            }
+            if (s3base + 2 * q + ks + 1 < n_steps) w_store(ks ^ 1);
+            __syncthreads();
+        }
+        float sv[16], bv[16];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float4 s4 = *reinterpret_cast<const float4 *>(p.bn + 256 + q * 64 + ch16 + 4 * v);
+            const float4 b4 = *reinterpret_cast<const float4 *>(p.bn + 256 + p.Cout + q * 64 + ch16 + 4 * v);
+            sv[4 * v] = s4.x * sc3; sv[4 * v + 1] = s4.y * sc3; sv[4 * v + 2] = s4.z * sc3; sv[4 * v + 3] = s4.w * sc3;
+            bv[4 * v] = b4.x; bv[4 * v + 1] = b4.y; bv[4 * v + 2] = b4.z; bv[4 * v + 3] = b4.w;
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b >= nb2) continue;
+            float m4 = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                chk = fmaf(acc[b][4 * v], 0.f, fmaf(acc[b][4 * v + 1], 0.f, fmaf(acc[b][4 * v + 2], 0.f, fmaf(acc[b][4 * v + 3], 0.f, chk))));
+                const float o0 = prelu(fmaf(acc[b][4 * v], sv[4 * v], bv[4 * v] + res[b][v].x), p.slope);
+                const float o1 = prelu(fmaf(acc[b][4 * v + 1], sv[4 * v + 1], bv[4 * v + 1] + res[b][v].y), p.slope);
+                const float o2 = prelu(fmaf(acc[b][4 * v + 2], sv[4 * v + 2], bv[4 * v + 2] + res[b][v].z), p.slope);
+                const float o3 = prelu(fmaf(acc[b][4 * v + 3], sv[4 * v + 3], bv[4 * v + 3] + res[b][v].w), p.slope);
+                m4 = fmaxf(fmaxf(m4, fmaxf(fabsf(o0), fabsf(o1))), fmaxf(fabsf(o2), fabsf(o3)));
+                u32x4 o;
+                o.x = __float_as_uint(o0); o.y = __float_as_uint(o1); o.z = __float_as_uint(o2); o.w = __float_as_uint(o3);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, opix[b] != kOOB ? opix[b] + chb + 16u * v : kOOB, 0, 0);
+            }
+            amax = fmaxf(amax, opix[b] != kOOB ? m4 : 0.f);
+        }
+    }
+    if (p.range_flag != nullptr && __any(!(chk == 0.f)) && lane == 0) atomicOr(p.range_flag, 1);
+    if (p.amax_out != nullptr) tsod_amax_commit(p.amax_out, amax, scr, tid, 256);
+}
+
+}  // namespace
+
+extern "C" size_t tsod_bottleneck_wstream_bytes(int32_t Cin, int32_t Cout) {
+    if (Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 64) return 0;
+    return (size_t)(Cin / 32 + 18 + (Cout / 64) * 2) * W_STEP;
+}
+
+extern "C" int tsod_bottleneck_fp16x2(const tsod_bottleneck_desc *d, const float *x, const void *wstream, const float *bn,
+                                      float *out, tsod_stream_t stream) {
+    TSOD_REQUIRE(d && x && wstream && bn && out, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE(d->Cmid == CMID && d->Cin % 32 == 0 && d->Cin >= 32 && d->Cout % 64 == 0 && d->Cout == d->Cin, TSOD_ERR_UNSUPPORTED);
+    TSOD_REQUIRE(d->in_pitch >= d->Cin && d->out_pitch >= d->Cout && (d->in_pitch & 3) == 0 && (d->out_pitch & 3) == 0, TSOD_ERR_ALIGNMENT);
+    TSOD_REQUIRE(tsod_aligned16(x) && tsod_aligned16(out) && tsod_aligned16(wstream) && tsod_aligned16(bn), TSOD_ERR_ALIGNMENT);
+    TSOD_REQUIRE((reinterpret_cast<uintptr_t>(d->amax_in) & 63u) == 0 && (reinterpret_cast<uintptr_t>(d->amax_out) & 63u) == 0, TSOD_ERR_ALIGNMENT);
+    TSOD_REQUIRE(d->a_scale_exp >= -24 && d->a_scale_exp <= 24, TSOD_ERR_INVALID_ARG);
+    TSOD_REQUIRE((uint64_t)d->N * d->H * d->W * d->in_pitch * 4 < 0xFFFFFFF0ull, TSOD_ERR_UNSUPPORTED);   // 32-bit byte offsets into x
+    Params p;
+    p.x = x; p.out = out; p.wstream = static_cast<const unsigned char *>(wstream); p.bn = bn;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_pitch = d->in_pitch; p.Cout = d->Cout; p.out_pitch = d->out_pitch;
+    p.tiles_x = (d->W + TW - 1) / TW; p.tiles_y = (d->H + TH - 1) / TH;
+    TSOD_REQUIRE((uint64_t)d->N * d->H * d->W * d->out_pitch * 4 < 0xFFFFFFF0ull && d->Cin % 64 == 0, TSOD_ERR_UNSUPPORTED);
+    p.x_bytes = (unsigned)((uint64_t)d->N * d->H * d->W * d->in_pitch * 4);
+    p.out_bytes = (unsigned)((uint64_t)d->N * d->H * d->W * d->out_pitch * 4);
+    p.slope = d->slope; p.w_exp1 = d->w_exp[0]; p.w_exp2 = d->w_exp[1]; p.w_exp3 = d->w_exp[2];
+    p.a_scale = ldexpf(1.f, d->a_scale_exp);
+    p.amax_in = d->amax_in; p.amax_out = d->amax_out; p.range_flag = d->range_flag;
+    static const int dbg = [] { const char *e = getenv("TSOD_BN_DBG"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg;
+    const int64_t grid = (int64_t)d->N * p.tiles_x * p.tiles_y;
+    TSOD_REQUIRE(grid < 0x7FFFFFFF, TSOD_ERR_UNSUPPORTED);
+    hipLaunchKernelGGL(bottleneck_kernel, dim3((unsigned)grid), dim3(256), 0, tsod_stream(stream), p);
+    return tsod_launch_status();
+}

@@ -81,6 +81,40 @@ class FusedShortcutConv:
         return H, W
 
 
+class FusedBottleneckWeights:
+    """An identity-shortcut bottleneck (models/resnet.py:57-76, stride 1, no downsample) packed for tsod_bottleneck_fp16x2: the
+    three convs' weights as one stream in consumption order, the three folded BatchNorms as one vector, the shared PReLU slope."""
+
+    def __init__(self, blk, device):
+        from . import hip_ops
+        c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
+        self.cin, self.cmid, self.cout = c1.in_channels, c1.out_channels, c3.out_channels
+        w1 = c1.weight.detach().float().to(device).view(self.cmid, self.cin)
+        w2 = hip_ops.pack_conv_weight(c2.weight.detach().float().to(device))            # [64, 3, 3, 64]
+        w3 = c3.weight.detach().float().to(device).view(self.cout, self.cmid)
+        self.stream, self.w_exps = hip_ops.pack_bottleneck_wstream(w1, w2, w3)
+        bn = []
+        for m in (blk.bn1, blk.bn2, blk.bn3):
+            bn.extend(fold_bn(m))
+        self.bn = torch.cat(bn).to(device)
+        self.slope = prelu_slope(blk.relu)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(self.stream.device).synchronize()
+
+
+class FusedStep:
+    """One tsod_bottleneck_fp16x2 launch of a plan, with what the timing / roofline code asks of a ConvStep."""
+    precision = _ffi.PREC_FP16X2
+
+    def __init__(self, name, fn, args, desc, flops, algorithmic_bytes):
+        self.name, self.fn, self.args, self.desc, self.flops, self.algorithmic_bytes = name, fn, args, desc, flops, algorithmic_bytes
+
+
+def step_precision(st) -> int:
+    """Arithmetic of a matrix launch of a plan (ConvStep or FusedStep): _ffi.PREC_*"""
+    return int(st.precision) if isinstance(st, FusedStep) else int(st.desc.precision)
+
+
 def weights_bf16x3(pc) -> torch.Tensor:
     """The pre-split bf16x3 image of a packed layer's weights (PackedConv or a compatible holder), made on first use and
     kept beside the f32 weights."""
@@ -99,9 +133,11 @@ def weights_bf16x3(pc) -> torch.Tensor:
 FP16X2_A_SCALE_EXP = 4     # static default (no range words): activations are split as 2^4 * x: |x| < 4094 (65504 / 16) is its range
 
 
-def new_range_flag() -> torch.Tensor:
-    """One int32 in pinned host memory (device-visible at the same address): what desc.range_flag points at."""
-    return torch.zeros(1, dtype=torch.int32).pin_memory()
+def new_range_flag(device) -> torch.Tensor:
+    """One int32 in device memory: what desc.range_flag points at.  (A word in pinned host memory, readable without a device round
+    trip, was tried and dropped: every reporting wave's atomic then crosses PCIe, and tuning launches on stale buffers - thousands
+    of reporting waves per launch - ran 100x slower and took the fp16x2 candidates out of the table.)"""
+    return torch.zeros(1, dtype=torch.int32, device=device)
 
 
 def fp16x2_activation_exp(absmax: float, headroom_bits: int = 4) -> int:
@@ -198,14 +234,15 @@ class Plan:
         self._retired: list = []             # outgrown workspaces: graphs captured earlier still hold their pointers
         self.steps: list[list] = []          # [cfunc, [args...]]
         self.conv_steps: list[ConvStep] = []
+        self.fused_steps: list[FusedStep] = []                   # whole-bottleneck launches (tsod_bottleneck_fp16x2)
+        self.gemm_steps: list = []           # every matrix launch in forward order: ConvStep | FusedStep (timing, roofline)
         self.keep: list = []                 # keeps descriptors / tensors alive
         self._ws_slots: list[tuple[list, int, int, int]] = []   # (args, ptr index, size index, bytes)
         self.workspace: torch.Tensor | None = None
         self.graph = None
-        # fp16x2 layers OR 1 into this word when a launch ends with non-finite accumulators (include/tsod.h: range_flag).  A word
-        # in pinned HOST memory, written by the rare launch that has something to report and read by the host without a device
-        # round trip (PlanOwner shares ONE word among all its plans, see _cached_plan)
-        self.range_flag = new_range_flag()
+        # fp16x2 layers OR 1 into this word when a launch ends with non-finite accumulators (include/tsod.h: range_flag);
+        # PlanOwner shares ONE word among all its plans (see _cached_plan): it survives plan eviction and costs one read
+        self.range_flag = new_range_flag(self.device)
         self.a_exps: dict = {}               # layer name -> fp16x2 activation exponent (calibrate_fp16x2); the owner shares ONE dict among its plans
         self.flops = 0
         self.on_calibrated = None
@@ -241,10 +278,21 @@ class Plan:
             self._amax_slot[t.untyped_storage().data_ptr()] = slot
 
     def clear_range_flag(self) -> None:
-        """Forget what launches issued so far reported (tuning / timing launches run on whatever the pooled buffers hold).  The
-        word lives in host memory: wait for those launches first."""
+        """Forget what launches issued so far reported (tuning / timing launches run on whatever the pooled buffers hold); waits
+        for launches on other streams first."""
         torch.cuda.synchronize(self.device)
-        self.range_flag.zero_()
+        with torch.inference_mode():
+            self.range_flag.zero_()
+
+    def _refresh_amax_for(self, st) -> None:
+        """Isolated timing of one layer (autotune's first look): the pooled buffer its input lives in may hold a LATER tensor of
+        the forward by now, or what earlier candidates left - make the input's range words describe the bytes that are there, so
+        that an fp16x2 candidate is timed on in-range operands like the ones it will meet (non-finite accumulators cost power
+        and reports, and would pick the table for the wrong reasons)."""
+        for t, a in ((st.x, st.desc.amax_in), (st.x2, st.desc.amax_in2)):
+            if t is not None and a:
+                check(lib().tsod_amax_reset(a, 1, stream_ptr()), "amax_reset")
+                check(lib().tsod_absmax_f32(ptr(t), t.numel(), a, stream_ptr()), "absmax")
 
     def reset_amax(self) -> None:
         """Zero the words in use (stream-ordered, capturable): first thing of every forward, before the input is staged."""
@@ -311,8 +359,35 @@ class Plan:
         st.flops = 2 * N * OH * OW * getattr(pc, "cout_real", pc.cout) * pc.kh * pc.kw_logical * pc.cin_src   # algorithmic
         st.ws_bytes = 0
         self.conv_steps.append(st)
+        self.gemm_steps.append(st)
         self.flops += st.flops
         self.keep.extend([d, x, out, pc, residual])
+        return out
+
+    def bottleneck(self, fb: "FusedBottleneckWeights", x: torch.Tensor, out: torch.Tensor, name: str):
+        """x [N,H,W,Cin] -> out [N,H,W,Cout]: conv1 + conv2 + conv3 + identity of a bottleneck as ONE launch (fp16x2; the input's
+        scale from its range words when the plan keeps them, the intermediates' from each tile's own abs-max)."""
+        N, H, W, P = x.shape
+        assert tuple(out.shape[:3]) == (N, H, W) and fb.cin == fb.cout
+        d = _ffi.BottleneckDesc()
+        d.N, d.H, d.W, d.Cin, d.in_pitch, d.Cmid, d.Cout, d.out_pitch = N, H, W, fb.cin, P, fb.cmid, fb.cout, out.shape[3]
+        d.slope = float(fb.slope)
+        for k in range(3):
+            d.w_exp[k] = int(fb.w_exps[k])
+        d.a_scale_exp = int(self.a_exps.get(name, FP16X2_A_SCALE_EXP))
+        d.range_flag = ptr(self.range_flag)
+        d.amax_in, d.amax_out = self.amax_ptr(x) or None, self.amax_ptr(out) or None
+        args = [byref(d), ptr(x), ptr(fb.stream), ptr(fb.bn), ptr(out)]
+        self.steps.append([lib().tsod_bottleneck_fp16x2, args])
+        px = N * H * W
+        flops = 2 * px * (fb.cin * fb.cmid + 9 * fb.cmid * fb.cmid + fb.cmid * fb.cout)
+        # what the block must move however it is computed: x in, out out, the weights (the residual is x again: counted once)
+        alg = 4 * (px * fb.cin + px * fb.cout + fb.cin * fb.cmid + 9 * fb.cmid * fb.cmid + fb.cmid * fb.cout)
+        st = FusedStep(name, self.steps[-1][0], args, d, flops, alg)
+        self.fused_steps.append(st)
+        self.gemm_steps.append(st)
+        self.flops += flops
+        self.keep.extend([d, x, out, fb])
         return out
 
     def finalize(self):
@@ -380,6 +455,23 @@ class Plan:
         else:
             self.launch()
 
+    def sequence_time(self, reps: int = 10) -> float:
+        """HIP-event time (ms) of ONE pass over the plan's matrix launches (convs and fused bottlenecks) in forward order, back to
+        back on the current stream, averaged over ``reps`` passes: every layer finds its input where the previous launch left it
+        and its weights as cold as a forward leaves them (what bench.py's roofline and FasterRCNN.tune's structure choice use)."""
+        s = stream_ptr()
+        for st in self.gemm_steps:
+            st.fn(*st.args, s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            for st in self.gemm_steps:
+                st.fn(*st.args, s)
+        e1.record()
+        e1.synchronize()
+        self.clear_range_flag()      # (these launches ran on whatever the pooled buffers held, not on a forward's activations)
+        return e0.elapsed_time(e1) / reps
+
     def capture(self):
         """Record the plan into a HIP graph (one graph launch per forward afterwards)."""
         torch.cuda.synchronize(self.device)
@@ -421,6 +513,7 @@ class Plan:
             K = d.KH * d.KW * sum(d.seg_len[i] for i in range(d.n_seg)) + max(0, int(d.c2))
             ksteps = (K + 31) // 32
             M = d.N * d.OH * d.OW
+            self._refresh_amax_for(st)
             cands = []
             for prec in (precisions if precisions is not None else (int(d.precision),)):
                 for tile in (_ffi.BF16X3_TILE_IDS if prec == _ffi.PREC_BF16X3 else (_ffi.FP16X2_TILE_IDS if prec == _ffi.PREC_FP16X2
@@ -584,6 +677,16 @@ class Plan:
             st.choose(tile, split, int(row[3]) if len(row) > 3 else 0)
         return self.finalize()
 
+    def import_tiles_by_name(self, tiles):
+        """Pin the rows of a table whose layer names this plan has (a table tuned on the same model with ANOTHER launch
+        structure, e.g. before some bottlenecks were fused); layers the table does not name keep their choice."""
+        by_name = {row[0]: row for row in tiles}
+        for st in self.conv_steps:
+            row = by_name.get(st.name)
+            if row is not None:
+                st.choose(row[1], row[2], int(row[3]) if len(row) > 3 else 0)
+        return self.finalize()
+
     def tile_choices(self):
         out = []
         for st in self.conv_steps:
@@ -696,9 +799,18 @@ class PlanOwner:
       is stale (it would run the old folded weights)."""
     max_plans = 8
     conv_precision = "f32"       # "f32" | "bf16x3" | "fp16x2": default arithmetic of the dense convs of plans built from now on
+    fuse_bottleneck = False      # ResNet: identity bottlenecks with 64 mid channels (layer1.1, layer1.2) as ONE launch each
+                                 # (tsod_bottleneck_fp16x2; FasterRCNN.tune switches it on where it measures faster)
     fuse_shortcut = True         # ResNet: a bottleneck's last 1x1 conv + its projection shortcut as one stacked-K GEMM
                                  # (set False + invalidate_packed() for the one-launch-per-conv plan, e.g. to pin a tile
                                  # table recorded from it)
+
+    def set_fuse_bottleneck(self, on: bool):
+        """Switch the one-launch bottlenecks on / off for plans built from now on (existing plans are dropped, packed weights stay)."""
+        if bool(on) != bool(self.fuse_bottleneck):
+            self.fuse_bottleneck = bool(on)
+            self.__dict__["_plans"] = OrderedDict()
+        return self
 
     def set_conv_precision(self, precision: str):
         """Arithmetic of the dense conv GEMMs: "f32" (v_mfma_f32_32x32x2_f32), "bf16x3" (three exact bf16 pieces per
@@ -713,21 +825,20 @@ class PlanOwner:
     def raise_if_error(self):
         """Surface what the fp16x2 launches of ANY plan of this owner reported since the last call (evicted plans included:
         the word belongs to the owner): a launch that ended with non-finite accumulators - non-finite input, or, for a conv
-        without range words, an activation beyond the static exponent's range; its outputs are garbage.  Waits for the device
-        (the word is host memory written by the launches), then one host read."""
+        without range words, an activation beyond the static exponent's range; its outputs are garbage.  One device read (a sync)."""
         flag = self.__dict__.get("_range_flag")
         if flag is None:
             return
-        torch.cuda.synchronize()
-        if int(flag[0]) != 0:
-            flag.zero_()
+        if int(flag.item()) != 0:
+            with torch.inference_mode():
+                flag.zero_()
             raise TsodError("fp16x2: a conv layer ended with non-finite accumulators - non-finite input (or, without range words, "
                             f"an activation beyond +-{65504 // (1 << FP16X2_A_SCALE_EXP)}); its outputs are garbage")
 
     def range_flag_raised(self) -> bool:
-        """The word itself, without waiting for anything: True once a launch that has COMPLETED reported (serving.result())."""
+        """The word as it is now (one 4-byte device read): True once a launch that has COMPLETED reported (serving.result())."""
         flag = self.__dict__.get("_range_flag")
-        return flag is not None and int(flag[0]) != 0
+        return flag is not None and int(flag.item()) != 0
 
     def _init_plan_owner(self):
         self.__dict__["_plans"] = OrderedDict()
@@ -774,6 +885,8 @@ class PlanOwner:
                 if int(st.desc.precision) == _ffi.PREC_FP16X2:    # (built in that arithmetic: choose() ran before the dict was shared)
                     st.desc.a_scale_exp = int(shared.get(st.name, FP16X2_A_SCALE_EXP))
                     st.desc.range_flag = ptr(flag)
+            for st in getattr(plan, "fused_steps", ()):
+                st.desc.range_flag = ptr(flag)
             while len(plans) > max(1, int(self.max_plans)):
                 plans.popitem(last=False)
         else:

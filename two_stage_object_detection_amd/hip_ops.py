@@ -231,6 +231,60 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
     return out
 
 
+def pack_bottleneck_wstream(w1: torch.Tensor, w2: torch.Tensor, w3: torch.Tensor):
+    """The weight stream of tsod_bottleneck_fp16x2 (include/tsod.h): w1 [64, Cin], w2 [64, 3, 3, 64] (packed conv layout:
+    [Cout][KH][KW][Cin]), w3 [Cout, 64], f32 on the GPU -> (uint8 tensor of tsod_bottleneck_wstream_bytes, (e1, e2, e3)).
+    Pure index arithmetic on the three matrices (done once per model; the fp16 roundings are torch's round-to-nearest-even,
+    the same bits as the device's v_cvt_pk_f16_f32)."""
+    dev = w1.device
+    cin, cout = w1.shape[1], w3.shape[0]
+    i = torch.arange(32)
+    pi = 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3)
+    rows = torch.cat([pi, 32 + pi]).to(dev)                                 # LDS row r = 32 cb + i  <-  channel 32 cb + pi(i)
+    r = torch.arange(64)
+    slot_src = (torch.arange(4).view(1, 4) ^ ((r >> 2) & 3).view(64, 1)).to(dev)   # stored slot s' holds logical slot s' ^ swz(r)
+
+    def steps(w2d, e):
+        """w2d [n_rows (multiple of 64), K (multiple of 32)] -> [n_rows/64 * K/32 steps, 8192 bytes], row-block-major then k"""
+        sc = w2d.float() * (2.0 ** e)
+        hi = sc.half()
+        lo = (sc - hi.float()).half()
+        out = []
+        for pl in (hi, lo):
+            nb, ks = pl.shape[0] // 64, pl.shape[1] // 32
+            t = pl.view(nb, 64, ks, 4, 8)[:, rows]                           # [nb, 64 lds rows, ks, 4 slots, 8]
+            t = torch.gather(t, 3, slot_src.view(1, 64, 1, 4, 1).expand(nb, 64, ks, 4, 8))
+            out.append(t.permute(0, 2, 1, 3, 4).reshape(nb * ks, 64 * 32).contiguous().view(torch.uint8))   # [steps, 4096 bytes]
+        return torch.cat(out, dim=1)                                         # hi plane | lo plane
+
+    e1, e2, e3 = (fp16x2_weight_scale_exp(w) for w in (w1, w2, w3))
+    s1 = steps(w1.reshape(64, cin), e1)
+    # conv2: step = (tap, channel half): K order of the packed layout is (kh, kw, ci), so k = 32 * (2 tap + half) already
+    s2 = steps(w2.reshape(64, 9 * 64), e2)
+    s3 = steps(w3.reshape(cout, 64), e3)                                     # row blocks of 64 output channels, 2 k-steps each
+    stream = torch.cat([s1, s2, s3], dim=0).contiguous().view(-1)
+    assert stream.numel() == lib().tsod_bottleneck_wstream_bytes(cin, cout)
+    return stream, (e1, e2, e3)
+
+
+def bottleneck_fused(x: torch.Tensor, wstream: torch.Tensor, w_exps, bn: torch.Tensor, cout: int, slope: float, *, out=None,
+                     a_scale_exp=4, amax_in=None, amax_out=None, range_flag=None) -> torch.Tensor:
+    """tsod_bottleneck_fp16x2 on an NHWC tensor x [N,H,W,P] (channels [0, cout) are the block's input): see include/tsod.h."""
+    require_cuda(x, "bottleneck_fused")
+    N, H, W, P = x.shape
+    if out is None:
+        out = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
+    d = _ffi.BottleneckDesc()
+    d.N, d.H, d.W, d.Cin, d.in_pitch, d.Cmid, d.Cout, d.out_pitch = N, H, W, cout, P, 64, cout, out.shape[3]
+    d.slope = float(slope)
+    for k in range(3):
+        d.w_exp[k] = int(w_exps[k])
+    d.a_scale_exp = int(a_scale_exp)
+    d.range_flag, d.amax_in, d.amax_out = ptr(range_flag) or None, _word_ptr(amax_in), _word_ptr(amax_out)
+    check(lib().tsod_bottleneck_fp16x2(byref(d), ptr(x), ptr(wstream), ptr(bn), ptr(out), stream_ptr()), "bottleneck_fused")
+    return out
+
+
 def _word_ptr(w):
     """None / a raw device pointer / a tensor of range words -> what the descriptor takes."""
     if w is None:

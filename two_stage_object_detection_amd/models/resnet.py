@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import hip_ops
 from .._ffi import ACT_NONE, ACT_PRELU, TsodError, lib, ptr, require_cuda
-from ..engine import FusedShortcutConv, PackedConv, Plan, PlanOwner, prelu_slope
+from ..engine import FusedBottleneckWeights, FusedShortcutConv, PackedConv, Plan, PlanOwner, prelu_slope
 
 
 def _conv(cin, cout, k, stride=1, pad=0, groups=1):
@@ -47,6 +47,14 @@ class _ResidualBlock(nn.Module):
                                                                       act=ACT_NONE))
             oh, ow = pc.out_hw(x.shape[1], x.shape[2])
             identity = plan.conv(pc, x, plan.pool.alloc((x.shape[0], oh, ow, pc.cout)), name=f"{name}.downsample")
+        # the whole block as ONE launch (tsod_bottleneck_fp16x2): identity shortcut, 64 mid channels, stride 1 - layer1.1 / layer1.2,
+        # the HBM-bound stage of the trunk (the 64-channel intermediates stay in LDS)
+        if (getattr(plan, "fuse_bottleneck", False) and self.downsample is None and len(self._stage_names) == 3
+                and self.conv1.out_channels == 64 and self.conv2.groups == 1 and self.conv2.stride == (1, 1)
+                and self.conv1.in_channels == self.conv3.out_channels and self.conv1.in_channels % 64 == 0):
+            fb = plan.packed(f"{name}.fused", lambda: FusedBottleneckWeights(self, dev))
+            out = plan.pool.alloc((x.shape[0], x.shape[1], x.shape[2], fb.cout))
+            return plan.bottleneck(fb, x, out, name=f"{name}.fused")
         cur = x
         last = len(self._stage_names) - 1
         for i, (cname, bname) in enumerate(self._stage_names):
@@ -169,6 +177,7 @@ class ResNet(PlanOwner, nn.Module):
         plan = Plan(device, self._packed_cache)
         plan.precision = {"f32": 0, "bf16x3": 1, "fp16x2": 2}[self.conv_precision]
         plan.fuse_shortcut = bool(self.fuse_shortcut)
+        plan.fuse_bottleneck = bool(self.fuse_bottleneck)
         x4 = plan.pool.alloc((N, H, W, 4))
         plan.input_nhwc = x4
         stem = plan.packed("conv1", lambda: PackedConv(self.conv1.weight, device, bn=self.bn1, stride=2, pad=3, act=ACT_PRELU,

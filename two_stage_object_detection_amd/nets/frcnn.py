@@ -111,7 +111,7 @@ class FasterRCNN(nn.Module):
             return rpn_choice, self.head.autotune(fc7)
 
     def tune(self, example, precisions=(0, 1, 2), in_flight=1, schedules=("serial", "in_flight"), splits=None, in_sequence=None,
-             in_flight_refine=None, reps=3, heads=True, verbose=False):
+             in_flight_refine=None, reps=3, heads=True, fuse_bottleneck="auto", verbose=False):
         """Autotune every GEMM of the forward for ``example``'s geometry ([B,3,H,W] on the GPU) and pin the result: per conv
         layer the fastest (tile, K-slice schedule, arithmetic) among ``precisions`` (0 f32 MFMA, 1 bf16x3, 2 fp16x2 - all three
         f32-accurate; the fp16x2 scale follows every tensor per forward through its range words, so no calibration pass and no
@@ -121,9 +121,12 @@ class FasterRCNN(nn.Module):
         timed again inside the conv sequence, ``in_sequence``); "in_flight" (only with ``in_flight`` > 1) = the objective of
         ``serving.InFlightDetector(depth=in_flight)``: candidates timed as that many copies side by side, then
         (``in_flight_refine``, default 3 below batch 4) re-tried with every slot's stream running the whole conv sequence.
-        Returns the tables as plain JSON-able data {"serial": [...], "in_flight": [...], "heads": {...}} - feed it back through
-        ``import_tuning`` (another process, another rank) or ``InFlightDetector(tiles=...)``.  Afterwards the plan of slot 0
-        runs the serial table when that was tuned, else the in-flight one."""
+        ``fuse_bottleneck`` ("auto" | True | False; needs fp16x2 among ``precisions``): ResNet's identity bottlenecks with 64 mid
+        channels as ONE launch each (tsod_bottleneck_fp16x2) - "auto" times one pass over the matrix launches with and without
+        and keeps the faster structure.
+        Returns the tables as plain JSON-able data {"serial": [...], "in_flight": [...], "heads": {...}, "fuse_bottleneck": bool}
+        - feed it back through ``import_tuning`` (another process, another rank) or ``InFlightDetector(tiles=...)``.  Afterwards
+        the plan of slot 0 runs the serial table when that was tuned, else the in-flight one."""
         from ..engine import refine_in_flight
         require_cuda(example, "FasterRCNN.tune")
         B = example.shape[0]
@@ -131,27 +134,60 @@ class FasterRCNN(nn.Module):
         in_flight_refine = (3 if B < 4 else 0) if in_flight_refine is None else in_flight_refine
         if splits is None and B >= 4:
             splits = [1, -1, -2, 2, 4]       # large M: tiles outnumber the chip's slots many times; deep K-slicing never wins there
+        want = [k for k in ("serial", "in_flight") if k in schedules and (k == "serial" or in_flight > 1)]
+        if not want:
+            raise TsodError("FasterRCNN.tune: nothing to tune (schedules / in_flight)")
+        ext = self.extractor
         table = {}
-        with torch.inference_mode():
-            self(example)                                           # builds the plan; leaves real activations (and range words) behind
-            plan = self.extractor._plan_for(example)
-            if "serial" in schedules:
+
+        def tune_schedule(plan, sched):
+            if sched == "serial":
                 plan.autotune(reps=reps, verbose=verbose, splits=splits, concurrent=1, precisions=precisions, in_sequence=in_sequence)
-                table["serial"] = plan.export_tiles()
-            if "in_flight" in schedules and in_flight > 1:
-                plan.autotune(reps=reps, verbose=False, splits=splits, concurrent=max(2, in_flight), precisions=precisions,
-                              keep_shortlist=in_flight_refine)
-                table["in_flight"] = plan.export_tiles()
-                if in_flight_refine > 0 and plan.last_shortlist:
-                    slot_plans = [plan]
-                    for sl in range(1, in_flight):
-                        self(example, slot=sl)
-                        slot_plans.append(self.extractor._plan_for(example, sl))
-                        slot_plans[-1].import_tiles(table["in_flight"])
-                    table["in_flight"] = refine_in_flight(slot_plans, plan.last_shortlist, verbose=verbose)
-            if not table:
-                raise TsodError("FasterRCNN.tune: nothing to tune (schedules / in_flight)")
+                return plan.export_tiles()
+            plan.autotune(reps=reps, verbose=False, splits=splits, concurrent=max(2, in_flight), precisions=precisions,
+                          keep_shortlist=in_flight_refine)
+            tiles = plan.export_tiles()
+            if in_flight_refine > 0 and plan.last_shortlist:
+                slot_plans = [plan]
+                for sl in range(1, in_flight):
+                    self(example, slot=sl)
+                    slot_plans.append(ext._plan_for(example, sl))
+                    slot_plans[-1].import_tiles(tiles)
+                tiles = refine_in_flight(slot_plans, plan.last_shortlist, verbose=verbose)
+            return tiles
+
+        with torch.inference_mode():
+            can_fuse = hasattr(ext, "set_fuse_bottleneck")
+            if can_fuse:
+                ext.set_fuse_bottleneck(False)                      # every layer first gets its own best kernel
+            self(example)                                           # builds the plan; leaves real activations (and range words) behind
+            plan = ext._plan_for(example)
+            table[want[0]] = tune_schedule(plan, want[0])
+            fused = False
+            if can_fuse and fuse_bottleneck and 2 in tuple(precisions):
+                t_plain = plan.sequence_time()
+                ext.set_fuse_bottleneck(True)
+                self(example)
+                plan_f = ext._plan_for(example)
+                if plan_f.fused_steps:
+                    plan_f.import_tiles_by_name(table[want[0]])
+                    t_fused = plan_f.sequence_time()
+                    fused = fuse_bottleneck is True or t_fused < t_plain
+                    if verbose:
+                        print(f"  one-launch bottlenecks ({len(plan_f.fused_steps)}): {t_fused * 1e3:.1f} us per pass against {t_plain * 1e3:.1f} us -> "
+                              f"{'fused' if fused else 'three launches each'}")
+                if fused:
+                    plan = plan_f
+                    table[want[0]] = plan.export_tiles()
+                else:
+                    ext.set_fuse_bottleneck(False)
+                    self(example)
+                    plan = ext._plan_for(example)
+                    plan.import_tiles(table[want[0]])
+            for sched in want[1:]:
+                table[sched] = tune_schedule(plan, sched)
             plan.import_tiles(table.get("serial") or table["in_flight"])
+            table["fuse_bottleneck"] = bool(fused)
             if heads:
                 self.autotune_heads(example)
                 table["heads"] = self.head_choices()
@@ -161,6 +197,8 @@ class FasterRCNN(nn.Module):
         """Pin a table made by ``tune`` (same model, same input geometry; e.g. rank 0's on every rank) in the plan of ``slot``."""
         require_cuda(example, "FasterRCNN.import_tuning")
         self.set_head_choices(table.get("heads"))
+        if hasattr(self.extractor, "set_fuse_bottleneck"):
+            self.extractor.set_fuse_bottleneck(bool(table.get("fuse_bottleneck", False)))
         with torch.inference_mode():
             self(example, slot=slot)
             self.extractor._plan_for(example, slot).import_tiles(table.get(schedule) or table["serial"])

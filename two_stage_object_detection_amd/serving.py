@@ -41,6 +41,8 @@ class InFlightDetector:
                 tiles = model.tune(example, in_flight=depth, schedules=("in_flight",) if depth > 1 else ("serial",))
             if isinstance(tiles, dict):
                 model.set_head_choices(tiles.get("heads"))
+                if hasattr(model.extractor, "set_fuse_bottleneck"):
+                    model.extractor.set_fuse_bottleneck(bool(tiles.get("fuse_bottleneck", False)))   # the table's launch structure
                 tiles = tiles.get("in_flight" if depth > 1 else "serial") or tiles.get("serial")
             model(example)                                               # builds slot 0's plan
             plan0 = model.extractor._plan_for(example, 0)
@@ -85,9 +87,9 @@ class InFlightDetector:
         if self._ticket_of[slot] != ticket:
             raise TsodError(f"InFlightDetector: ticket {ticket} is no longer resident (its slot was reused)")
         self._done[slot].synchronize()
-        # the conv launches' range word is host memory (engine.new_range_flag): a plain read, no device round trip.  A set word
-        # means SOME forward that has completed on this detector ran an fp16x2 layer into non-finite accumulators (non-finite
-        # input): this step's outputs may be garbage - never hand them out as valid.
+        # the conv launches' range word (one 4-byte device read: ~10 us of host time per request, nothing on the GPU's critical
+        # path).  A set word means SOME forward that has completed on this detector ran an fp16x2 layer into non-finite
+        # accumulators (non-finite input): this step's outputs may be garbage - never hand them out as valid.
         if self.model.extractor.range_flag_raised():
             self.model.extractor.raise_if_error()
         return self._outputs[slot]
