@@ -91,6 +91,9 @@ def parse(argv=None):
                     "in its range words (per forward, inside the launches: any finite input range) - all three f32-accurate and "
                     "gated by the same parity suite; auto (default) = the autotuner picks per layer among all three; "
                     "auto-bf16x3 = among f32 and bf16x3 only (rounds 2-3)")
+    ap.add_argument("--fuse-bottleneck", default="auto", choices=("auto", "on", "off"), help="ResNet layer1's identity bottlenecks as one "
+                    "launch each (tsod_bottleneck_fp16x2): auto = FasterRCNN.tune times one pass over the matrix launches with and "
+                    "without and keeps the faster structure")
     ap.add_argument("--autotune-splits", default=None, help="comma list restricting the K-slice candidates of the autotuner")
     ap.add_argument("--autotune-in-sequence", type=int, default=None, help="serial tile table: the n fastest candidates of every layer "
                     "(timed in isolation) are timed again as launches of the whole conv sequence and the winner THERE is pinned "
@@ -551,6 +554,7 @@ def main(argv=None):
             while time.perf_counter() - t_w < 1.5:
                 conv_sequence_time(plan, reps=20)
         precs = {"f32": (0,), "bf16x3": (1,), "auto-bf16x3": (0, 1), "auto": (0, 1, 2), "fp16x2": (0, 1, 2)}[args.precision]
+        fuse_arg = {"auto": "auto", "on": True, "off": False}[args.fuse_bottleneck]
         # The tuning goes through the public call (FasterRCNN.tune): what a user of the module surface gets is what is timed.
         # fp16x2 needs no calibration pass: its activation scale follows every tensor per forward (range words).
         if tiles_loaded:
@@ -560,11 +564,11 @@ def main(argv=None):
             # run the same kernels in the same summation order; start-up stays far inside the driver's limit)
             if rank == 0:
                 tiles = model.tune(x, precisions=precs, in_flight=n_fly, schedules=("in_flight",) if n_fly > 1 else ("serial",),
-                                   splits=splits, in_sequence=0, in_flight_refine=0, verbose=args.verbose)
+                                   splits=splits, in_sequence=0, in_flight_refine=0, verbose=args.verbose, fuse_bottleneck=fuse_arg)
                 tiles["serial"] = tiles["in_flight"] = tiles.get("in_flight") or tiles["serial"]
         elif not args.no_autotune:
             tiles = model.tune(x, precisions=precs, in_flight=n_fly, splits=splits, in_sequence=args.autotune_in_sequence,
-                               in_flight_refine=args.autotune_in_flight_refine, verbose=args.verbose and rank == 0)
+                               in_flight_refine=args.autotune_in_flight_refine, verbose=args.verbose and rank == 0, fuse_bottleneck=fuse_arg)
             tiles.setdefault("in_flight", tiles["serial"])
         tuning_s = time.perf_counter() - t_tune
         if world > 1:

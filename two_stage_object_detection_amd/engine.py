@@ -10,6 +10,7 @@ Data layout in HBM: every activation is NHWC f32, channel pitch a multiple of 4,
 """
 from __future__ import annotations
 
+import os
 import re
 
 from collections import OrderedDict
@@ -255,7 +256,9 @@ class Plan:
         self.pool.on_alloc = self._new_amax_slot
 
     # -- range words ------------------------------------------------------------------------
-    DEFAULT_DYNAMIC_SCALE = True             # False: plans built from now on use the static fp16x2 exponents (calibrate_fp16x2)
+    # False: plans built from now on use the static fp16x2 exponents (calibrate_fp16x2).  TSOD_NO_RANGE_WORDS=1 switches the words off
+    # for A/B timing (scripts/ab_env.sh); the static 2^4 exponent covers the synthetic detector's activations
+    DEFAULT_DYNAMIC_SCALE = os.environ.get("TSOD_NO_RANGE_WORDS", "0") in ("", "0")
     AMAX_SLOTS = 320                         # tensors per forward (ResNet-101: ~110, HarDNet-85: ~200); 4 KB each
 
     def _new_amax_slot(self, t: torch.Tensor) -> None:
