@@ -211,11 +211,12 @@ int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, const float
  * the scale of each tile's own abs-max.  This build: Cmid == 64, Cin == Cout, both multiples of 64.
  *
  * `wstream`: the three convs' weights as ONE stream of 8 KB steps in consumption order - Cin/32 steps of conv1 (k = 32 s ..),
- * 18 of conv2 (step = (tap kh*3+kw, channel half)), 2 per 64 output channels of conv3 - each step the LDS image of
- * [64 rows][32 k] fp16 of 2^w_exp[i] * w as two planes (hi at +0, lo at +4096; lo = rne(2^e w - hi)): row r = 32 cb + i holds
- * output channel base + 32 cb + pi(i), pi(i) = 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3); a row is 4 slots of 8 k, slot s stored
- * at slot s ^ ((r >> 2) & 3) (bank swizzle).  `bn`: f32 [s1(64) | b1(64) | s2(64) | b2(64) | s3(Cout) | b3(Cout)], the folded
- * BatchNorm scale / shift of the three convs.  No workspace. */
+ * 18 of conv2 (step = (tap kh*3+kw, channel half)), 2 per 64 output channels of conv3 - each step 64 output channels x 32 k of
+ * fp16 pieces of 2^w_exp[i] * w (hi = rne(.), lo = rne(2^e w - hi)), stored as the MFMA fragments the kernel's lanes load
+ * straight from L2 into registers: [channel block cb (2)][lane (64) = 32 hh + j][chunk c (2)][hi | lo][8 k], where lane (j, hh) of
+ * block cb holds output channel base + 32 cb + pi(j), pi(j) = 16 ((j >> 2) & 1) + 4 (j >> 3) + (j & 3) (so that an accumulator
+ * lane owns 16 consecutive channels), and k = 16 c + 8 hh ...  `bn`: f32 [s1(64) | b1(64) | s2(64) | b2(64) | s3(Cout) | b3(Cout)],
+ * the folded BatchNorm scale / shift of the three convs.  No workspace. */
 typedef struct tsod_bottleneck_desc {
     int32_t N, H, W;              /* images, height, width (input and output) */
     int32_t Cin, in_pitch;        /* x: [N][H][W][in_pitch], channels [0, Cin) */

@@ -326,10 +326,10 @@ def test_compare_detector_outputs_is_one_to_one():
 
 
 def test_bottleneck_weight_stream_layout():
-    """hip_ops.pack_bottleneck_wstream against the layout include/tsod.h documents (what bottleneck_kernel's fragment reads
-    assume): 8 KB steps in consumption order (conv1's K-steps, conv2's (tap, channel half) steps, conv3's 64-channel slices x 2
-    K-steps); inside a step two planes (hi at +0, lo at +4096) of [64 rows][4 slots of 8 k]; row 32 cb + i holds channel
-    32 cb + pi(i); slot s is stored at s ^ ((row >> 2) & 3); hi + lo reproduce 2^e * w to fp16x2 accuracy."""
+    """hip_ops.pack_bottleneck_wstream against the layout include/tsod.h documents (what bottleneck_kernel's lanes load): 8 KB
+    steps in consumption order (conv1's K-steps, conv2's (tap, channel half) steps, conv3's 64-channel slices x 2 K-steps); a
+    step = [channel block cb][lane = 32 hh + j][chunk c][hi | lo][8 k]: lane (j, hh) of block cb holds output channel
+    32 cb + pi(j), k = 16 c + 8 hh ..; hi + lo reproduce 2^e * w to fp16x2 accuracy."""
     from two_stage_object_detection_amd import hip_ops
     g = torch.Generator().manual_seed(5)
     cin = cout = 128
@@ -339,22 +339,22 @@ def test_bottleneck_weight_stream_layout():
     stream, (e1, e2, e3) = hip_ops.pack_bottleneck_wstream(w1, w2, w3)
     n1, n3 = cin // 32, (cout // 64) * 2
     assert stream.dtype == torch.uint8 and stream.numel() == (n1 + 18 + n3) * 8192
-    steps = stream.view(-1, 2, 64, 4, 8 * 2).view(torch.float16).view(-1, 2, 64, 4, 8)        # [step][plane][row][stored slot][8 k]
+    steps = stream.view(torch.float16).view(-1, 2, 64, 2, 2, 8)   # [step][cb][lane][chunk][plane][8 k]
 
-    def row_channel(r):
-        cb, i = r // 32, r % 32
-        return 32 * cb + 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3)
+    def pi(j):
+        return 16 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3)
 
     def check(step, w_rows_k, e):
         """w_rows_k [64 channels of the step, 32 k]"""
-        for r in (0, 1, 5, 17, 31, 32, 44, 63):
-            for slot in range(4):
-                stored = slot ^ ((r >> 2) & 3)
-                hi, lo = steps[step, 0, r, stored].float(), steps[step, 1, r, stored].float()
-                want = w_rows_k[row_channel(r), 8 * slot:8 * slot + 8] * (2.0 ** e)
-                assert torch.equal(hi, want.half().float())
-                assert torch.equal(lo, (want - want.half().float()).half().float())
-                assert float((hi + lo - want).abs().max()) <= float(want.abs().max()) * 2.0 ** -21
+        for cb in (0, 1):
+            for lane in (0, 1, 5, 17, 31, 32, 44, 63):
+                j, hh = lane & 31, lane >> 5
+                for c in (0, 1):
+                    hi, lo = steps[step, cb, lane, c, 0].float(), steps[step, cb, lane, c, 1].float()
+                    want = w_rows_k[32 * cb + pi(j), 16 * c + 8 * hh:16 * c + 8 * hh + 8] * (2.0 ** e)
+                    assert torch.equal(hi, want.half().float())
+                    assert torch.equal(lo, (want - want.half().float()).half().float())
+                    assert float((hi + lo - want).abs().max()) <= float(want.abs().max()) * 2.0 ** -21
     for ks in range(n1):
         check(ks, w1[:, 32 * ks:32 * ks + 32], e1)
     w2f = w2.reshape(64, 576)
@@ -367,6 +367,6 @@ def test_bottleneck_weight_stream_layout():
             check(n1 + 18 + 2 * q + ks, w3[64 * q:64 * q + 64, 32 * ks:32 * ks + 32], e3)
     # a lane of the accumulator owns 16 CONSECUTIVE channels: rows 4 h + (e & 3) + 8 (e >> 2) of a block are channels 16 h + e
     for h in (0, 1):
-        assert [row_channel(4 * h + (e & 3) + 8 * (e >> 2)) for e in range(16)] == list(range(16 * h, 16 * h + 16))
+        assert [pi(4 * h + (e & 3) + 8 * (e >> 2)) for e in range(16)] == list(range(16 * h, 16 * h + 16))
     for m in (max(abs(float(w.abs().max()) * 2.0 ** e) for w, e in ((w1, e1), (w2, e2), (w3, e3))),):
         assert 8192.0 <= m < 16384.0                                # every weight matrix scaled to just below 2^14

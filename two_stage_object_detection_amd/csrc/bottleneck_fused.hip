@@ -42,11 +42,11 @@ constexpr int CMID = 64;
 // 16-byte bank groups without an XOR, so a fragment address is ONE per-lane base + an immediate offset - tap shift, channel slot and
 // plane are all compile-time in the unrolled loops)
 constexpr int Y_PITCH = 144, Y_PLANE = 224 * Y_PITCH;
-constexpr int A_PLANE = 224 * 64;                // one fp16 plane of conv1's x stage: [224 rows][32 k], XOR-swizzled (inside the y region)
-constexpr int Y_BYTES = 2 * Y_PLANE;             // 64 512
-constexpr int W_STEP = 8192;                     // one weight step: [64 rows][32 k] x (hi, lo)
-constexpr int W_OFF = Y_BYTES, SCR_OFF = W_OFF + 2 * W_STEP, LDS_BYTES = SCR_OFF + 64;
-static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+constexpr int A_PLANE = 224 * 64, A_STAGE = 2 * A_PLANE;   // conv1's x stage: two fp16 planes of [224 rows][32 k], XOR-swizzled; two stages
+constexpr int Y_BYTES = 2 * Y_PLANE;             // 64 512 (>= 2 x-stages of 28 672)
+constexpr int W_STEP = 8192;                     // one weight step: 64 output channels x 32 k x (hi, lo)
+constexpr int SCR_OFF = Y_BYTES, LDS_BYTES = SCR_OFF + 64;
+static_assert(2 * A_STAGE <= Y_BYTES && 2 * LDS_BYTES <= 160 * 1024, "x stages inside the y region; two workgroups per CU");
 constexpr unsigned kOOB = 0xFFFFFFF0u;           // byte offset beyond any buffer-descriptor extent: loads return 0, stores are dropped
 
 struct Params {
@@ -85,8 +85,7 @@ __device__ __forceinline__ void mfma3(f32x16 &acc, const u32x4 &wh, const u32x4 
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, ah), acc, 0, 0, 0);
 }
 
-// byte offset of 16-byte slot `slot` of row `row` in the XOR-swizzled 64-byte-row tiles (x stage, weight steps: 4 slots per row, 4 rows
-// per 256-byte bank line)
+// byte offset of 16-byte slot `slot` of row `row` in the XOR-swizzled 64-byte-row x stage (4 slots per row, 4 rows per bank line)
 __device__ __forceinline__ int off64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
 // workgroup-wide max of a non-negative value through LDS (two barriers); every thread gets it
@@ -103,6 +102,10 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// the weight fragments of one step for one wave: chunk c (16 k): hi, lo
+struct WFrag { u32x4 h[2], l[2]; };
+struct AFrag { u32x4 h, l; };
+
 __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
     __shared__ __align__(16) unsigned char lds[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,9 +114,8 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
     const int nb1 = pb0 == 0 ? 4 : 3, nb2 = pb0 == 0 ? 3 : 2;   // pixel blocks this wave owns: of the halo's 7, of the tile's 5
     float *scr = reinterpret_cast<float *>(lds + SCR_OFF);
 
-    // ---- the tile
-    // blocks b, b + 8, ... share an XCD (private L2; observed round-robin placement - a speed matter only): XCD x takes a contiguous
-    // run of the tile order, so that neighbouring tiles - which share halo pixels - are read through ONE L2
+    // ---- the tile.  Blocks b, b + 8, ... share an XCD (private L2; observed round-robin placement - a speed matter only): XCD x takes
+    // a contiguous run of the tile order, so that neighbouring tiles - which share halo pixels - are read through ONE L2
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int nwg = (int)gridDim.x, per = nwg >> 3, r8 = nwg & 7, xcd = (int)blockIdx.x & 7;
     const int tile_id = (xcd < r8 ? xcd * (per + 1) : r8 * (per + 1) + (xcd - r8) * per) + ((int)blockIdx.x >> 3);
@@ -134,27 +136,19 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
     }
     a_scale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(a_scale)));
 
-    // ---- weight stream: step s = 8 KB, thread t copies 16-byte units t and t + 256 into ring slot (s & 1)
+    // ---- weight stream: step s = 8 KB = [channel block cb][lane][chunk 0 hi | chunk 0 lo | chunk 1 hi | chunk 1 lo]: a lane's four
+    // fragments of a step are 64 contiguous bytes, a wave's 4 KB - straight from L2 into registers (no LDS ring: no barrier per
+    // step, and the weights are the same 272 KB for every workgroup of the launch: L2-resident), two steps ahead of their use
     const int n_steps1 = p.Cin / 32, n_steps = n_steps1 + 18 + (p.Cout / 64) * 2;
-    u32x4 wr0, wr1;
-    auto w_load = [&](int s) {
-        if ((p.dbg & 4) && s > 1) return;
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(p.wstream + (size_t)s * W_STEP);
-        wr0 = src[tid];
-        wr1 = src[tid + 256];
+    const u32x4 *wbase = reinterpret_cast<const u32x4 *>(p.wstream + cb * (W_STEP / 2) + lane * 64);
+    auto w_load = [&](int s, WFrag &f) {
+        if (s >= n_steps || ((p.dbg & 4) && s > 2)) return;
+        const u32x4 *src = wbase + (size_t)s * (W_STEP / 16);
+        f.h[0] = src[0]; f.l[0] = src[1]; f.h[1] = src[2]; f.l[1] = src[3];
     };
-    auto w_store = [&](int slot) {
-        u32x4 *dst = reinterpret_cast<u32x4 *>(lds + W_OFF + slot * W_STEP);
-        dst[tid] = wr0;
-        dst[tid + 256] = wr1;
-    };
-    // weight fragments of this wave's channel block: row cb * 32 + j, chunk c = slots 2 c + hh (XOR-swizzled): two per-lane addresses;
-    // ring slot and plane are immediate offsets
-    const unsigned char *wfa[2] = {lds + W_OFF + off64(cb * 32 + j, hh), lds + W_OFF + off64(cb * 32 + j, 2 + hh)};
-    auto w_frag = [&](int slot, int c, u32x4 &wh, u32x4 &wl) {
-        wh = *reinterpret_cast<const u32x4 *>(wfa[c] + slot * W_STEP);
-        wl = *reinterpret_cast<const u32x4 *>(wfa[c] + slot * W_STEP + W_STEP / 2);
-    };
+    WFrag wf[3];                                         // steps s, s + 1, s + 2 rotate through these (compile-time indices only)
+    w_load(0, wf[0]);
+    w_load(1, wf[1]);
 
     // ---- conv1's x stage: 224 rows x 8 float4 per K-step = 7 float4 per thread; unit u = tid + 256 i: row = u >> 3, quad = u & 7
     unsigned xoff[7];                                  // byte offset of the unit in x at K-step 0 (kOOB: outside the image / padding row)
@@ -170,26 +164,26 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
     }
     float4 xr[7];
     auto x_load = [&](int ks) {
-        if ((p.dbg & 1) && ks > 0) return;
+        if (ks >= n_steps1 || ((p.dbg & 1) && ks > 0)) return;
 #pragma unroll
         for (int i = 0; i < 7; ++i) xr[i] = bload4(rs_x, xoff[i] != kOOB ? xoff[i] + (unsigned)ks * 128u : kOOB);
     };
-    auto x_store = [&]() {
+    auto x_store = [&](int stage) {
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             unsigned h0_, l0_, h1_, l1_;
             split2(xr[i].x, xr[i].y, a_scale, h0_, l0_);
             split2(xr[i].z, xr[i].w, a_scale, h1_, l1_);
-            *reinterpret_cast<uint2 *>(lds + xdst[i]) = make_uint2(h0_, h1_);
-            *reinterpret_cast<uint2 *>(lds + A_PLANE + xdst[i]) = make_uint2(l0_, l1_);
+            *reinterpret_cast<uint2 *>(lds + stage * A_STAGE + xdst[i]) = make_uint2(h0_, h1_);
+            *reinterpret_cast<uint2 *>(lds + stage * A_STAGE + A_PLANE + xdst[i]) = make_uint2(l0_, l1_);
         }
     };
     // x fragments of the wave's pixel blocks: row (pb0 + 2 b) * 32 + j, chunk c
-    const unsigned char *xfa[4][2];
+    int xfa[4][2];                                       // (LDS byte offsets, not pointers: a pointer into LDS costs two registers)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) xfa[b][c] = lds + off64((pb0 + 2 * b) * 32 + j, 2 * c + hh);
+        for (int c = 0; c < 2; ++c) xfa[b][c] = off64((pb0 + 2 * b) * 32 + j, 2 * c + hh);
 
     // ================= conv1: y1[224 x 64] = x_halo[224 x Cin] . W1^T =================
     f32x16 acc[4];
@@ -197,40 +191,39 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
     for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
-    w_load(0);
     x_load(0);
-    w_store(0);
-    x_store();
+    x_store(0);
+    x_load(1);
     __syncthreads();
-    // one step: weights from ring slot SLOT (compile-time), x stage -> MFMAs; behind it the next step's operands go into LDS
-    auto conv1_step = [&](auto SLOT, int ks) {
-        constexpr int slot = decltype(SLOT)::value;
-        w_load(ks + 1);                                  // (conv2's first step behind conv1's last)
-        if (ks + 1 < n_steps1) x_load(ks + 1);
+    // step ks: x stage (ks & 1) -> MFMAs, while stage (ks + 1) & 1 is filled from the registers (loaded one step ago) and the loads of
+    // step ks + 2 go out; ONE barrier per step.  The weights of steps ks, ks + 1, ks + 2 sit in wf[0], wf[1], wf[2]: a step ends by
+    // moving them down one place (register moves; a rotation by index would need the loop unrolled by six, which the register
+    // allocator answers with 250+ spilled registers).
+    auto conv1_step = [&](auto STAGE, int ks) {
+        constexpr int stage = decltype(STAGE)::value;
+        w_load(ks + 2, wf[2]);
+        if (ks + 1 < n_steps1) x_store(stage ^ 1);
+        x_load(ks + 2);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            u32x4 wh, wl;
-            w_frag(slot, c, wh, wl);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 if (b < nb1) {
-                    const u32x4 ah = *reinterpret_cast<const u32x4 *>(xfa[b][c]);
-                    const u32x4 al = *reinterpret_cast<const u32x4 *>(xfa[b][c] + A_PLANE);
-                    mfma3(acc[b], wh, wl, ah, al);
+                    const u32x4 ah = *reinterpret_cast<const u32x4 *>(lds + xfa[b][c] + stage * A_STAGE);
+                    const u32x4 al = *reinterpret_cast<const u32x4 *>(lds + xfa[b][c] + stage * A_STAGE + A_PLANE);
+                    mfma3(acc[b], wf[0].h[c], wf[0].l[c], ah, al);
                 }
             }
         }
-        __syncthreads();                                 // every wave is done with the x stage (and with ring slot `slot`'s predecessor)
-        w_store(slot ^ 1);
-        if (ks + 1 < n_steps1) {
-            x_store();
-            __syncthreads();
-        }
+        wf[0] = wf[1];
+        wf[1] = wf[2];
+        __syncthreads();
     };
     for (int ks = 0; ks < n_steps1; ks += 2) {           // (Cin is a multiple of 64: an even number of steps)
         conv1_step(std::integral_constant<int, 0>{}, ks);
         conv1_step(std::integral_constant<int, 1>{}, ks + 1);
     }
+    // (wf[0], wf[1] now hold conv2's first two steps)
     // ---- y1 = PReLU(BN1(.)), zero outside the image (conv2's zero padding pads y1, not x), tile-wide scale, pieces into LDS
     // acc[b][e]: pixel row (pb0 + 2 b) * 32 + j of the halo, channel cb * 32 + 16 hh + e
     const int ch16 = cb * 32 + 16 * hh;
@@ -259,14 +252,14 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
             }
         }
     }
-    mx = block_max(mx, scr, tid);                        // (its first barrier also orders the x stage's last reads before the y1 writes)
+    mx = block_max(mx, scr, tid);                        // (its barriers also order the x stages' last reads before the y1 writes)
     const int e1 = tsod_fp16x2_exp_from_bits(__float_as_uint(mx));
     const float ys1 = __uint_as_float((unsigned)(127 + e1) << 23);
     auto y_store = [&](const f32x16 &v, int row, float ysc) {
         unsigned hq[8], lq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) split2(v[2 * e], v[2 * e + 1], ysc, hq[e], lq[e]);
-        unsigned char *dst = lds + row * Y_PITCH + (4 * cb + 2 * hh) * 16;
+        unsigned char *dst = lds + (row * Y_PITCH + (4 * cb + 2 * hh) * 16);
         *reinterpret_cast<u32x4 *>(dst) = u32x4{hq[0], hq[1], hq[2], hq[3]};
         *reinterpret_cast<u32x4 *>(dst + 16) = u32x4{hq[4], hq[5], hq[6], hq[7]};
         *reinterpret_cast<u32x4 *>(dst + Y_PLANE) = u32x4{lq[0], lq[1], lq[2], lq[3]};
@@ -278,41 +271,49 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
     __syncthreads();
 
     // ================= conv2: y2[160 x 64] = im2col(y1)[160 x 576] . W2^T (18 steps: tap, channel half) =================
-    // this lane's output pixels (one per owned pixel block): the address of its halo row at tap (0, 0), k half included
-    const unsigned char *yfa[3];
+    // No barrier inside: y1 is read-only, the weights come from registers.  The fragments of chunk n + 1 are read while chunk n's MFMAs
+    // run (two register sets), the weights of step t + 2 are requested at step t.
+    int yfa[3];                                          // this lane's output pixels: LDS offset of the halo row at tap (0, 0), k half included
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         int pidx = (pb0 + 2 * b) * 32 + j;
         pidx = pidx < TH * TW ? pidx : TH * TW - 1;      // (rows of a block past the tile compute a duplicate, never stored)
-        yfa[b] = lds + ((pidx / TW) * HW_ + (pidx % TW)) * Y_PITCH + hh * 16;
+        yfa[b] = ((pidx / TW) * HW_ + (pidx % TW)) * Y_PITCH + hh * 16;
     }
 #pragma unroll
     for (int b = 0; b < 3; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
-    const int s2base = n_steps1;                          // (even: conv2's step t sits in ring slot t & 1)
+    const int s2base = n_steps1;
+    AFrag af[2][3];
+    auto y1_frags = [&](int n, AFrag (&f)[3]) {          // chunk n = 2 t + c of conv2: tap t >> 1, channels 32 (t & 1) + 16 c
+        const int t = n >> 1, c = n & 1, tap = t >> 1, kh = tap / 3, kw = tap - kh * 3;
+        const int imm = (kh * HW_ + kw) * Y_PITCH + (t & 1) * 64 + c * 32;            // an immediate after unrolling
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            if (b < nb2) {
+                f[b].h = *reinterpret_cast<const u32x4 *>(lds + yfa[b] + imm);
+                f[b].l = *reinterpret_cast<const u32x4 *>(lds + yfa[b] + imm + Y_PLANE);
+            }
+    };
+    y1_frags(0, af[0]);
 #pragma unroll
     for (int t = 0; t < 18; ++t) {
-        w_load(s2base + t + 1);
-        const int tap = t >> 1, kh = tap / 3, kw = tap - kh * 3;
-        const int imm = (kh * HW_ + kw) * Y_PITCH + (t & 1) * 64;      // tap shift + channel half: an immediate after unrolling
+        w_load(s2base + t + 2, wf[(t + 2) % 3]);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            u32x4 wh, wl;
-            w_frag(t & 1, c, wh, wl);
+            const int n = 2 * t + c;
+            if (n + 1 < 36) y1_frags(n + 1, af[(n + 1) & 1]);
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                if (b < nb2) {
-                    const u32x4 ah = *reinterpret_cast<const u32x4 *>(yfa[b] + imm + c * 32);
-                    const u32x4 al = *reinterpret_cast<const u32x4 *>(yfa[b] + imm + c * 32 + Y_PLANE);
-                    mfma3(acc[b], wh, wl, ah, al);
-                }
-            }
+            for (int b = 0; b < 3; ++b)
+                if (b < nb2) mfma3(acc[b], wf[t % 3].h[c], wf[t % 3].l[c], af[n & 1][b].h, af[n & 1][b].l);
+            __builtin_amdgcn_sched_barrier(0);           // (the unrolled loop is one basic block: keep the scheduler from hoisting every
+                                                         //  later chunk's loads to the top - 400+ live registers, scratch spills)
         }
-        w_store((t & 1) ^ 1);                            // that slot was last read in step t - 1: a barrier ago
-        __syncthreads();
     }
-    // ---- y2 = PReLU(BN2(.)) -> pieces into the y region (y1 is dead: every wave is past the last step's barrier)
+    // (18 steps: conv3's first two steps sit in slots 0 and 1 again)
+    __syncthreads();                                     // every wave is done reading y1: the region takes y2
+    // ---- y2 = PReLU(BN2(.)) -> pieces into the y region
     const float sc2 = __uint_as_float((unsigned)(127 - e1 - p.w_exp2) << 23);
     mx = 0.f;
     {
@@ -344,11 +345,12 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
     __syncthreads();
 
     // ================= conv3: out[160 x Cout] = y2[160 x 64] . W3^T + x, 64 output channels (two weight steps) at a time ======
+    // No barrier inside either (y2 is read-only, weights from registers); y2 fragments are re-read per slice, chunk n + 1 under chunk
+    // n's MFMAs like conv2's.
     const float sc3 = __uint_as_float((unsigned)(127 - e2 - p.w_exp3) << 23);
     float amax = 0.f;
-    // this lane's output pixels: byte offsets of the pixel's channel 0 in x and in out, its y2 row
-    unsigned xpix[3], opix[3];
-    const unsigned char *y2a[3];
+    unsigned xpix[3], opix[3];                           // this lane's output pixels: byte offsets of channel 0 in x and in out
+    int y2a[3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         const int pidx = (pb0 + 2 * b) * 32 + j, pr = pidx / TW, pc = pidx - pr * TW;
@@ -356,40 +358,40 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
         const long gp = ((long)img * p.H + h0 + pr) * p.W + w0 + pc;
         xpix[b] = ok ? (unsigned)(gp * p.in_pitch) * 4u : kOOB;
         opix[b] = ok ? (unsigned)(gp * p.out_pitch) * 4u : kOOB;
-        y2a[b] = lds + pidx * Y_PITCH + hh * 16;
+        y2a[b] = pidx * Y_PITCH + hh * 16;
     }
-    const int s3base = n_steps1 + 18;                    // (even)
+    auto y2_frags = [&](int n, AFrag (&f)[3]) {          // chunk n (16 channels of y2)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            if (b < nb2) {
+                f[b].h = *reinterpret_cast<const u32x4 *>(lds + y2a[b] + n * 32);
+                f[b].l = *reinterpret_cast<const u32x4 *>(lds + y2a[b] + n * 32 + Y_PLANE);
+            }
+    };
+    const int s3base = n_steps1 + 18;
+    // one 64-channel slice per iteration: its two weight steps sit in wf[0], wf[1]; the next slice's first step is requested into wf[2]
+    // at the start, its second into wf[0] as soon as that is dead (after two chunks); the slice ends by moving them into place
     for (int q = 0; q < p.Cout / 64; ++q) {
 #pragma unroll
         for (int b = 0; b < 3; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
         const unsigned chb = (unsigned)(q * 64 + ch16) * 4u;            // byte offset of this lane's 16 channels inside a pixel
-        if (s3base + 2 * q + 1 < n_steps) w_load(s3base + 2 * q + 1);    // (the weights first: in-order returns - they are needed first)
-        // the residual of this 64-channel slice: issued before the MFMAs, consumed behind them
-        float4 res[3][4];
+        w_load(s3base + 2 * q + 2, wf[2]);                               // (the weights first: in-order returns - they are needed first)
+        float4 res[3][4];                                                // the residual of this slice: requested before the MFMAs
 #pragma unroll
         for (int b = 0; b < 3; ++b)
 #pragma unroll
             for (int v = 0; v < 4; ++v) res[b][v] = bload4(rs_x, (xpix[b] != kOOB && !(p.dbg & 2)) ? xpix[b] + chb + 16u * v : kOOB);
+        y2_frags(0, af[0]);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (ks == 1 && s3base + 2 * q + 2 < n_steps) w_load(s3base + 2 * q + 2);
+        for (int n = 0; n < 4; ++n) {
+            if (n == 2) w_load(s3base + 2 * q + 3, wf[0]);
+            if (n + 1 < 4) y2_frags(n + 1, af[(n + 1) & 1]);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                u32x4 wh, wl;
-                w_frag(ks, c, wh, wl);
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    if (b < nb2) {
-                        const u32x4 ah = *reinterpret_cast<const u32x4 *>(y2a[b] + ks * 64 + c * 32);
-                        const u32x4 al = *reinterpret_cast<const u32x4 *>(y2a[b] + ks * 64 + c * 32 + Y_PLANE);
-                        mfma3(acc[b], wh, wl, ah, al);
-                    }
-                }
-            }
-            if (s3base + 2 * q + ks + 1 < n_steps) w_store(ks ^ 1);
-            __syncthreads();
+            for (int b = 0; b < 3; ++b)
+                if (b < nb2) mfma3(acc[b], wf[n >> 1].h[n & 1], wf[n >> 1].l[n & 1], af[n & 1][b].h, af[n & 1][b].l);
+            __builtin_amdgcn_sched_barrier(0);
         }
         float sv[16], bv[16];
 #pragma unroll
@@ -417,6 +419,8 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
             }
             amax = fmaxf(amax, opix[b] != kOOB ? m4 : 0.f);
         }
+        wf[1] = wf[0];
+        wf[0] = wf[2];
     }
     if (p.range_flag != nullptr && __any(!(chk == 0.f)) && lane == 0) atomicOr(p.range_flag, 1);
     if (p.amax_out != nullptr) tsod_amax_commit(p.amax_out, amax, scr, tid, 256);

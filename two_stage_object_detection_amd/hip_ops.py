@@ -233,29 +233,28 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
 
 def pack_bottleneck_wstream(w1: torch.Tensor, w2: torch.Tensor, w3: torch.Tensor):
     """The weight stream of tsod_bottleneck_fp16x2 (include/tsod.h): w1 [64, Cin], w2 [64, 3, 3, 64] (packed conv layout:
-    [Cout][KH][KW][Cin]), w3 [Cout, 64], f32 on the GPU -> (uint8 tensor of tsod_bottleneck_wstream_bytes, (e1, e2, e3)).
+    [Cout][KH][KW][Cin]), w3 [Cout, 64], f32 -> (uint8 tensor of tsod_bottleneck_wstream_bytes, (e1, e2, e3)).
     Pure index arithmetic on the three matrices (done once per model; the fp16 roundings are torch's round-to-nearest-even,
-    the same bits as the device's v_cvt_pk_f16_f32)."""
+    the same bits as the device's v_cvt_pk_f16_f32).  A step (64 output channels x 32 k) is stored as the MFMA fragments the
+    kernel's lanes load: [channel block cb (2)][lane (64) = 32 hh + j][chunk c (2)][hi | lo][8 k] fp16, where lane (j, hh) holds
+    output channel 32 cb + pi(j) and k = 16 c + 8 hh .. + 7."""
     dev = w1.device
     cin, cout = w1.shape[1], w3.shape[0]
     i = torch.arange(32)
     pi = 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3)
-    rows = torch.cat([pi, 32 + pi]).to(dev)                                 # LDS row r = 32 cb + i  <-  channel 32 cb + pi(i)
-    r = torch.arange(64)
-    slot_src = (torch.arange(4).view(1, 4) ^ ((r >> 2) & 3).view(64, 1)).to(dev)   # stored slot s' holds logical slot s' ^ swz(r)
+    rows = torch.cat([pi, 32 + pi]).to(dev)                                 # fragment row 32 cb + j  <-  channel 32 cb + pi(j)
 
     def steps(w2d, e):
         """w2d [n_rows (multiple of 64), K (multiple of 32)] -> [n_rows/64 * K/32 steps, 8192 bytes], row-block-major then k"""
         sc = w2d.float() * (2.0 ** e)
         hi = sc.half()
         lo = (sc - hi.float()).half()
-        out = []
-        for pl in (hi, lo):
-            nb, ks = pl.shape[0] // 64, pl.shape[1] // 32
-            t = pl.view(nb, 64, ks, 4, 8)[:, rows]                           # [nb, 64 lds rows, ks, 4 slots, 8]
-            t = torch.gather(t, 3, slot_src.view(1, 64, 1, 4, 1).expand(nb, 64, ks, 4, 8))
-            out.append(t.permute(0, 2, 1, 3, 4).reshape(nb * ks, 64 * 32).contiguous().view(torch.uint8))   # [steps, 4096 bytes]
-        return torch.cat(out, dim=1)                                         # hi plane | lo plane
+        nb, ks = sc.shape[0] // 64, sc.shape[1] // 32
+        # [nb, cb, j, ks, c, hh, 8] for each plane
+        pl = torch.stack([t.view(nb, 64, ks, 2, 2, 8)[:, rows].view(nb, 2, 32, ks, 2, 2, 8) for t in (hi, lo)], dim=0)   # [plane, nb, cb, j, ks, c, hh, 8]
+        # -> [nb, ks, cb, hh, j, c, plane, 8]
+        out = pl.permute(1, 4, 2, 6, 3, 5, 0, 7).contiguous()
+        return out.view(nb * ks, 64 * 64).view(torch.uint8)                  # 4096 halves = 8192 bytes per step
 
     e1, e2, e3 = (fp16x2_weight_scale_exp(w) for w in (w1, w2, w3))
     s1 = steps(w1.reshape(64, cin), e1)
@@ -313,12 +312,13 @@ def absmax(x: torch.Tensor, words: torch.Tensor) -> torch.Tensor:
 def tune_conv(x: torch.Tensor, w_packed: torch.Tensor, reps: int = 5, precisions=(0, 1), **kw) -> tuple[int, int, int]:
     """Time every (tile, K-slice schedule, arithmetic) of ONE conv2d_nhwc call on its real operands with HIP events and return
     the fastest as (tile, split_k, precision) - for the few GEMMs outside a backbone plan (the fused RPN conv, the fused head
-    GEMM).  A speed choice only: every candidate is f32-accurate."""
+    GEMM).  A speed choice only: every candidate is f32-accurate.  Precision 2 (fp16x2) among ``precisions`` needs ``w2`` /
+    ``w_scale_exp`` and - for a range-proof scale - ``amax_in`` in ``kw`` (they are ignored by the other arithmetics)."""
     K = w_packed.numel() // w_packed.shape[0]
     ksteps = (K + 31) // 32
     best = None
     for prec in precisions:
-        for tile in (_ffi.BF16X3_TILE_IDS if prec == _ffi.PREC_BF16X3 else _ffi.TILE_IDS):
+        for tile in (_ffi.BF16X3_TILE_IDS if prec == _ffi.PREC_BF16X3 else (_ffi.FP16X2_TILE_IDS if prec == _ffi.PREC_FP16X2 else _ffi.TILE_IDS)):
             for split in (1, -1, -2, 2, 3, 4, 6, 8, 12, 16, 24, 32):
                 if split > 1 and ksteps // split < 2:
                     continue

@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from .. import hip_ops
+from .. import _ffi, hip_ops
 from .._ffi import TsodError, require_cuda
 from ..engine import PlanOwner
 from ..models.hardnet import HarNetClassifier
@@ -85,37 +85,70 @@ class HarNetRoIHead(PlanOwner, nn.Module):
                 torch.cuda.current_stream(dev).synchronize()       # complete before another slot's stream uses it
         return w3
 
-    def forward_nhwc(self, feat, rois, roi_indices, img_size):
-        """feat NHWC [n,Hf,Wf,C]; rois [n,R,4] image coords; roi_indices [n]; img_size (H,W) (quirk Q2)."""
+    def _w2(self, dev):
+        """(fp16x2 image, exponent) of the fused weight, made once and kept beside it like the bf16x3 image."""
+        w2 = self._packed_cache.get(("head.w2", dev))
+        if w2 is None:
+            w = self._pack(dev)[0]
+            e = hip_ops.fp16x2_weight_scale_exp(w)
+            w2 = self._packed_cache[("head.w2", dev)] = (hip_ops.pack_conv_weight_fp16x2(w.view(w.shape[0], 1, 1, w.shape[1]), e), e)
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(dev).synchronize()
+        return w2
+
+    def _gemm_kw(self, dev, prec, feat_amax, range_flag):
+        if prec == _ffi.PREC_BF16X3:
+            return {"w3": self._w3(dev)}
+        if prec == _ffi.PREC_FP16X2:
+            if not feat_amax:
+                raise TsodError("HarNetRoIHead: the fp16x2 arithmetic needs the feature map's range words; pin another arithmetic")
+            w2, e = self._w2(dev)
+            # the pooled means are bounded by the feature map's abs-max: its words give a safe scale
+            return {"w2": w2, "w_scale_exp": e, "amax_in": feat_amax, "range_flag": range_flag}
+        return {}
+
+    def pooled(self, feat, rois, roi_indices, img_size):
+        """RoI rescale + RoIPool / RoIAlign 7x7 + the classifier's mean: [n*R, C] (one launch)."""
+        n = feat.shape[0]
+        rois = rois.reshape(n, -1, 4)
+        if isinstance(self.roi, RoIAlign):
+            return hip_ops.roi_align_avg_nhwc(feat, rois, roi_indices, img_size[0], img_size[1], self.roi.output_size,
+                                              self.roi.spatial_scale, self.roi.sampling_ratio, self.roi.aligned)
+        return hip_ops.roi_pool_avg_nhwc(feat, rois, roi_indices, img_size[0], img_size[1], self.roi.output_size,
+                                         self.roi.spatial_scale)
+
+    def forward_nhwc(self, feat, rois, roi_indices, img_size, feat_amax=None, range_flag=None):
+        """feat NHWC [n,Hf,Wf,C]; rois [n,R,4] image coords; roi_indices [n]; img_size (H,W) (quirk Q2).  ``feat_amax``: the
+        range words of ``feat`` (what an fp16x2 choice of the fused GEMM scales its input with)."""
         require_cuda(feat, "HarNetRoIHead")
         if not isinstance(self.classifier, HarNetClassifier):
             raise TsodError("only the reference's HarNetClassifier (mean over the 7x7 bins) has a HIP path")
         n = feat.shape[0]
-        rois = rois.reshape(n, -1, 4)
-        if isinstance(self.roi, RoIAlign):
-            fc7 = hip_ops.roi_align_avg_nhwc(feat, rois, roi_indices, img_size[0], img_size[1], self.roi.output_size,
-                                             self.roi.spatial_scale, self.roi.sampling_ratio, self.roi.aligned)
-        else:
-            fc7 = hip_ops.roi_pool_avg_nhwc(feat, rois, roi_indices, img_size[0], img_size[1], self.roi.output_size,
-                                            self.roi.spatial_scale)
+        fc7 = self.pooled(feat, rois, roi_indices, img_size)
         w, b, n_loc, n_sc = self._pack(feat.device)
         # the fused Linear as a 1x1 "conv" over M = n*R rows: same GEMM kernel as tsod_linear_f32, with the tile / K-slice /
         # arithmetic choice of autotune() when there is one
         M, K = fc7.shape
         tile, split, prec = self.__dict__.get("_gemm_choice", {}).get(M, (0, 0, 0))
         both = hip_ops.conv2d_nhwc(fc7.view(1, 1, M, K), w.view(w.shape[0], 1, 1, K), shift=b, tile=tile, split_k=split,
-                                   precision=prec, w3=self._w3(feat.device) if prec else None
+                                   precision=prec, **self._gemm_kw(feat.device, prec, feat_amax, range_flag)
                                    ).view(M, w.shape[0])                           # [n*R, pad4(5*n_class)]
         # views into the fused output (row pitch 408 for 81 classes): same values and shapes as the reference's two
         # Linear outputs; .contiguous() them if a consumer needs dense storage
         return both[:, :n_loc].view(n, -1, n_loc), both[:, n_loc:n_loc + n_sc].view(n, -1, n_sc)
 
-    def autotune(self, fc7: torch.Tensor):
-        """Pin the fastest (tile, K-slice schedule, arithmetic) of the fused cls_loc + score GEMM for M = fc7.shape[0] RoIs."""
+    def autotune(self, fc7: torch.Tensor, feat_amax=None, range_flag=None):
+        """Pin the fastest (tile, K-slice schedule, arithmetic) of the fused cls_loc + score GEMM for M = fc7.shape[0] RoIs
+        (``fc7``: pooled RoI features of a real forward; fp16x2 among the candidates when the feature map's range words are given)."""
         w, b, _, _ = self._pack(fc7.device)
         M, K = fc7.shape
+        kw = {"w3": self._w3(fc7.device)}
+        precisions = (0, 1)
+        if feat_amax:
+            kw.update(self._gemm_kw(fc7.device, _ffi.PREC_FP16X2, feat_amax, range_flag))
+            precisions = (0, 1, 2)
         self.__dict__.setdefault("_gemm_choice", {})[M] = hip_ops.tune_conv(fc7.view(1, 1, M, K), w.view(w.shape[0], 1, 1, K), shift=b,
-                                                                             w3=self._w3(fc7.device))
+                                                                             precisions=precisions, **kw)
         return self._gemm_choice[M]
 
     def forward(self, x, rois, roi_indices, img_size):

@@ -76,6 +76,11 @@ class FasterRCNN(nn.Module):
             t = cache[(n, device)] = torch.arange(n, dtype=torch.int32, device=device)
         return t
 
+    def _feature_words(self, x, slot):
+        """(range words of the backbone's output for this input geometry / slot or None, the extractor's range word)."""
+        plan = self.extractor._plan_for(x, slot)
+        return (getattr(plan, "output_amax", 0) or None), self.extractor.__dict__.get("_range_flag")
+
     def forward(self, x, scale=1., mode="forward", slot=0):
         """``slot`` (added, non-breaking) selects an independent set of backbone buffers, so that forwards issued on
         different HIP streams can be in flight together."""
@@ -83,9 +88,11 @@ class FasterRCNN(nn.Module):
             require_cuda(x, "FasterRCNN.forward")
             with hip_ops.ARENA.scope((self._uid, slot)):          # scratch owned by (detector, slot), not by the stream
                 feat = self.extractor.forward_nhwc(x, slot)
-                _, rois, _ = self.rpn.propose(feat, tuple(x.shape[1:]), scale)
+                feat_amax, flag = self._feature_words(x, slot)    # (what an fp16x2 choice of the two GEMMs below scales with)
+                _, rois, _ = self.rpn.propose(feat, tuple(x.shape[1:]), scale, feat_amax=feat_amax, range_flag=flag)
                 roi_indices = self._roi_indices(x.shape[0], x.device)
-                roi_cls_locs, roi_scores = self.head.forward_nhwc(feat, rois, roi_indices, tuple(x.shape[2:]))
+                roi_cls_locs, roi_scores = self.head.forward_nhwc(feat, rois, roi_indices, tuple(x.shape[2:]), feat_amax=feat_amax,
+                                                                  range_flag=flag)
             return roi_cls_locs, roi_scores, rois, roi_indices
         elif mode == "extractor":
             return self.extractor.forward(x)
@@ -103,12 +110,14 @@ class FasterRCNN(nn.Module):
         """Time the candidates of the two GEMMs outside the backbone plan (fused RPN conv, fused head GEMM) for this input
         geometry and pin the fastest (``extractor._plan_for(x).autotune()`` does the same for the backbone)."""
         require_cuda(x, "FasterRCNN.autotune_heads")
-        with torch.inference_mode():
+        with torch.inference_mode(), hip_ops.ARENA.scope((self._uid, slot)):
             feat = self.extractor.forward_nhwc(x, slot)
-            rpn_choice = self.rpn.autotune(feat)
-            n_post = self.rpn.proposal_layer.counts()[1]
-            fc7 = torch.randn(x.shape[0] * n_post, self.head.cls_loc.in_features, device=x.device)
-            return rpn_choice, self.head.autotune(fc7)
+            feat_amax, flag = self._feature_words(x, slot)
+            rpn_choice = self.rpn.autotune(feat, feat_amax, flag)
+            # the head's GEMM on the pooled features of THIS forward (real values: the fp16x2 candidates then run in range)
+            _, rois, _ = self.rpn.propose(feat, tuple(x.shape[1:]), 1., feat_amax=feat_amax, range_flag=flag)
+            fc7 = self.head.pooled(feat, rois, self._roi_indices(x.shape[0], x.device), tuple(x.shape[2:]))
+            return rpn_choice, self.head.autotune(fc7, feat_amax, flag)
 
     def tune(self, example, precisions=(0, 1, 2), in_flight=1, schedules=("serial", "in_flight"), splits=None, in_sequence=None,
              in_flight_refine=None, reps=3, heads=True, fuse_bottleneck="auto", verbose=False):

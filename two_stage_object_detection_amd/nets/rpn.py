@@ -18,9 +18,9 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from .. import hip_ops
+from .. import _ffi, hip_ops
 from .._ffi import ACT_NONE, TsodError, require_cuda
-from ..engine import PackedConv, PlanOwner, weights_bf16x3
+from ..engine import PackedConv, PlanOwner, weights_bf16x3, weights_fp16x2
 from ..utils._config import load_config
 from ..utils.basic_anchors import generate_basic_anchor
 
@@ -111,25 +111,45 @@ class RegionProposalNetwork(PlanOwner, nn.Module):
                 torch.as_tensor(self.anchor_base, dtype=torch.float32).to(dev).contiguous(), n_loc, n_sc)
         return ent
 
-    def propose(self, feat: torch.Tensor, img_size, scale=1., want_anchors=False):
+    def _conv_kw(self, pc, prec, feat_amax, range_flag):
+        """Arguments of the fused conv that depend on the arithmetic: the pre-split weight image kept beside the f32 weights
+        (never re-split per call: a constant of a captured graph) and, for fp16x2, the feature map's range words."""
+        if prec == _ffi.PREC_BF16X3:
+            return {"w3": weights_bf16x3(pc)}
+        if prec == _ffi.PREC_FP16X2:
+            if not feat_amax:
+                raise TsodError("RegionProposalNetwork: the fp16x2 arithmetic needs the feature map's range words (a backbone plan "
+                                "with dynamic_scale); pin another arithmetic for this GEMM")
+            w2, e = weights_fp16x2(pc)
+            return {"w2": w2, "w_scale_exp": e, "amax_in": feat_amax, "range_flag": range_flag}
+        return {}
+
+    def propose(self, feat: torch.Tensor, img_size, scale=1., want_anchors=False, feat_amax=None, range_flag=None):
         """feat NHWC [n,h,w,C] -> (fused conv output [n*h*w, pad4(6A)] with loc in columns [0,4A) and score in
-        [4A,6A), rois [n,n_post,4], anchors [h*w*A,4] or None).  Four launches, no host sync."""
+        [4A,6A), rois [n,n_post,4], anchors [h*w*A,4] or None).  Four launches, no host sync.  ``feat_amax``: the range words
+        of ``feat`` (engine.Plan.output_amax) - what an fp16x2 choice of the fused conv takes its activation scale from."""
         require_cuda(feat, "RegionProposalNetwork")
         n, h, w, _ = feat.shape
         pc, base, n_loc, n_sc = self._pack(feat.device)
         tile, split, prec = self.__dict__.get("_gemm_choice", {}).get((n, h, w), (0, 0, 0))
         fused = hip_ops.conv2d_nhwc(feat, pc.w, shift=pc.shift, tile=tile, split_k=split, precision=prec,
-                                    w3=weights_bf16x3(pc) if prec else None).view(n * h * w, pc.cout)
+                                    **self._conv_kw(pc, prec, feat_amax, range_flag)).view(n * h * w, pc.cout)
         boxes, _, keys, anchor = hip_ops.rpn_decode(fused[:, :n_loc], fused[:, n_loc:n_loc + n_sc], base, n, h, w,
                                                     self.feat_stride, img_size[1], img_size[2],
                                                     self.proposal_layer.min_size * scale, want_anchors=want_anchors)
         return fused, self.proposal_layer.select(boxes, keys), anchor
 
-    def autotune(self, feat: torch.Tensor):
-        """Pin the fastest (tile, K-slice schedule, arithmetic) of the fused loc + score GEMM for this feature geometry."""
+    def autotune(self, feat: torch.Tensor, feat_amax=None, range_flag=None):
+        """Pin the fastest (tile, K-slice schedule, arithmetic) of the fused loc + score GEMM for this feature geometry
+        (fp16x2 among the candidates when the feature map's range words are given)."""
         n, h, w, _ = feat.shape
         pc = self._pack(feat.device)[0]
-        self.__dict__.setdefault("_gemm_choice", {})[(n, h, w)] = hip_ops.tune_conv(feat, pc.w, shift=pc.shift, w3=weights_bf16x3(pc))
+        kw = {"w3": weights_bf16x3(pc)}
+        precisions = (0, 1)
+        if feat_amax:
+            kw.update(self._conv_kw(pc, _ffi.PREC_FP16X2, feat_amax, range_flag))
+            precisions = (0, 1, 2)
+        self.__dict__.setdefault("_gemm_choice", {})[(n, h, w)] = hip_ops.tune_conv(feat, pc.w, shift=pc.shift, precisions=precisions, **kw)
         return self._gemm_choice[(n, h, w)]
 
     def forward_nhwc(self, feat: torch.Tensor, img_size, scale=1.):
