@@ -36,17 +36,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TH = 10, TW = 16, HW_ = TW + 2, HALO = (TH + 2) * (TW + 2);   // 216 halo pixels
+// Tile: TH x 16 output pixels, TH = 10 (160 pixels = 5 blocks of 32, halo 12 x 18 = 216 -> 224 rows = 7 blocks) or 8 (128 = 4 blocks,
+// halo 180 -> 192 rows = 6 blocks).  10 rows make one round of a batch-1 launch (420 tiles on 512 slots); 8 rows split evenly over the
+// waves (3 + 3 halo blocks, 2 + 2 tile blocks: the slowest wave issues 456 MFMAs for 128 pixels instead of 660 for 160) and win
+// from two images on.  The launcher picks by rounds x MFMAs of the slowest wave.
+constexpr int TW = 16, HW_ = TW + 2;
 constexpr int CMID = 64;
-// y planes: [224 rows][64 channels] fp16 at a pitch of 144 bytes (9 x 16: the 16 rows of a ds_read_b128 lane group land in 16 distinct
+// y planes: [rows][64 channels] fp16 at a pitch of 144 bytes (9 x 16: the 16 rows of a ds_read_b128 lane group land in 16 distinct
 // 16-byte bank groups without an XOR, so a fragment address is ONE per-lane base + an immediate offset - tap shift, channel slot and
 // plane are all compile-time in the unrolled loops)
-constexpr int Y_PITCH = 144, Y_PLANE = 224 * Y_PITCH;
-constexpr int A_PLANE = 224 * 64, A_STAGE = 2 * A_PLANE;   // conv1's x stage: two fp16 planes of [224 rows][32 k], XOR-swizzled; two stages
-constexpr int Y_BYTES = 2 * Y_PLANE;             // 64 512 (>= 2 x-stages of 28 672)
+constexpr int Y_PITCH = 144;
 constexpr int W_STEP = 8192;                     // one weight step: 64 output channels x 32 k x (hi, lo)
-constexpr int SCR_OFF = Y_BYTES, LDS_BYTES = SCR_OFF + 64;
-static_assert(2 * A_STAGE <= Y_BYTES && 2 * LDS_BYTES <= 160 * 1024, "x stages inside the y region; two workgroups per CU");
+template <int TH> struct Geo {
+    static constexpr int HALO = (TH + 2) * (TW + 2);             // halo pixels
+    static constexpr int PB1 = (HALO + 31) / 32, PB2 = TH * TW / 32;     // pixel blocks of 32: halo, tile
+    static constexpr int Y_PLANE = PB1 * 32 * Y_PITCH;           // one fp16 plane of y1
+    static constexpr int A_PLANE = PB1 * 32 * 64, A_STAGE = 2 * A_PLANE;   // conv1's x stage: two fp16 planes of [rows][32 k], XOR-swizzled
+    static constexpr int Y_BYTES = 2 * Y_PLANE, SCR_OFF = Y_BYTES, LDS_BYTES = SCR_OFF + 64;
+    static_assert(TH * TW % 32 == 0 && 2 * A_STAGE <= Y_BYTES && 2 * LDS_BYTES <= 160 * 1024, "x stages inside the y region; two workgroups per CU");
+};
 constexpr unsigned kOOB = 0xFFFFFFF0u;           // byte offset beyond any buffer-descriptor extent: loads return 0, stores are dropped
 
 struct Params {
@@ -106,12 +114,17 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
 struct WFrag { u32x4 h[2], l[2]; };
 struct AFrag { u32x4 h, l; };
 
+template <int TH>
 __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
+    using G = Geo<TH>;
+    constexpr int HALO = G::HALO, PB1 = G::PB1, PB2 = G::PB2, Y_PLANE = G::Y_PLANE, A_PLANE = G::A_PLANE, A_STAGE = G::A_STAGE,
+                  SCR_OFF = G::SCR_OFF, LDS_BYTES = G::LDS_BYTES;
     __shared__ __align__(16) unsigned char lds[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;             // fragment column (pixel) / row (weight row) index, k half
     const int cb = wave & 1, pb0 = wave >> 1;            // this wave's channel block of the step's 64, its first pixel block (stride 2)
-    const int nb1 = pb0 == 0 ? 4 : 3, nb2 = pb0 == 0 ? 3 : 2;   // pixel blocks this wave owns: of the halo's 7, of the tile's 5
+    // pixel blocks this wave owns (pb0, pb0 + 2, ...): of the halo's PB1, of the tile's PB2
+    const int nb1 = (PB1 - pb0 + 1) / 2, nb2 = (PB2 - pb0 + 1) / 2;
     float *scr = reinterpret_cast<float *>(lds + SCR_OFF);
 
     // ---- the tile.  Blocks b, b + 8, ... share an XCD (private L2; observed round-robin placement - a speed matter only): XCD x takes
@@ -150,11 +163,12 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
     w_load(0, wf[0]);
     w_load(1, wf[1]);
 
-    // ---- conv1's x stage: 224 rows x 8 float4 per K-step = 7 float4 per thread; unit u = tid + 256 i: row = u >> 3, quad = u & 7
-    unsigned xoff[7];                                  // byte offset of the unit in x at K-step 0 (kOOB: outside the image / padding row)
-    int xdst[7];                                       // byte offset of the unit's 8 bytes inside an x-stage plane
+    // ---- conv1's x stage: PB1 * 32 rows x 8 float4 per K-step = PB1 float4 per thread; unit u = tid + 256 i: row = u >> 3, quad = u & 7
+    constexpr int NX = PB1;
+    unsigned xoff[NX];                                  // byte offset of the unit in x at K-step 0 (kOOB: outside the image / padding row)
+    int xdst[NX];                                       // byte offset of the unit's 8 bytes inside an x-stage plane
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < NX; ++i) {
         const int u = tid + 256 * i, row = u >> 3, q = u & 7;
         const int hr = row / HW_, hc = row - hr * HW_;
         const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
@@ -162,15 +176,15 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
         xoff[i] = ok ? (unsigned)((((long)img * p.H + gh) * p.W + gw) * p.in_pitch + q * 4) * 4u : kOOB;
         xdst[i] = off64(row, q >> 1) + (q & 1) * 8;
     }
-    float4 xr[7];
+    float4 xr[NX];
     auto x_load = [&](int ks) {
         if (ks >= n_steps1 || ((p.dbg & 1) && ks > 0)) return;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) xr[i] = bload4(rs_x, xoff[i] != kOOB ? xoff[i] + (unsigned)ks * 128u : kOOB);
+        for (int i = 0; i < NX; ++i) xr[i] = bload4(rs_x, xoff[i] != kOOB ? xoff[i] + (unsigned)ks * 128u : kOOB);
     };
     auto x_store = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < NX; ++i) {
             unsigned h0_, l0_, h1_, l1_;
             split2(xr[i].x, xr[i].y, a_scale, h0_, l0_);
             split2(xr[i].z, xr[i].w, a_scale, h1_, l1_);
@@ -349,17 +363,31 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
     // n's MFMAs like conv2's.
     const float sc3 = __uint_as_float((unsigned)(127 - e2 - p.w_exp3) << 23);
     float amax = 0.f;
-    unsigned xpix[3], opix[3];                           // this lane's output pixels: byte offsets of channel 0 in x and in out
+    // Epilogue layout.  An accumulator lane holds 16 channels of ONE pixel: stored from there, every 16-byte piece of an instruction
+    // lands in a 64-byte segment of its own (measured: the stores cost 15 us of a 73 us tile at batch 1 - four times the L2 requests
+    // of a coalesced pass).  So each 32 pixel x 32 channel block goes through a wave-private LDS patch (the y region has two gaps of
+    // 9 KB behind y2's 160 rows: two patches of 32 x 144 bytes each) and comes back with 8 lanes per pixel: residual loads and output
+    // stores are whole 128-byte row segments, and the BatchNorm vectors are one float4 pair per lane.
+    constexpr int P_PITCH = 144, P_BYTES = 32 * P_PITCH;
+    static_assert(2 * P_BYTES <= Y_PLANE - TH * TW * Y_PITCH, "two patches per gap of the y region");
+    unsigned char *patch = lds + (wave >> 1) * Y_PLANE + TH * TW * Y_PITCH + (wave & 1) * P_BYTES;
+    const int ep_px = lane >> 3, ep_q = lane & 7;        // this lane's pixel (+ 8 i) and 4-channel piece of a block in the coalesced layout
     int y2a[3];
+    unsigned xpix[3][4], opix[3][4];                     // byte offsets of the lane's piece in x and in out (kOOB: not a pixel of the image)
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-        const int pidx = (pb0 + 2 * b) * 32 + j, pr = pidx / TW, pc = pidx - pr * TW;
-        const bool ok = b < nb2 && pidx < TH * TW && h0 + pr < p.H && w0 + pc < p.W;
-        const long gp = ((long)img * p.H + h0 + pr) * p.W + w0 + pc;
-        xpix[b] = ok ? (unsigned)(gp * p.in_pitch) * 4u : kOOB;
-        opix[b] = ok ? (unsigned)(gp * p.out_pitch) * 4u : kOOB;
-        y2a[b] = pidx * Y_PITCH + hh * 16;
+        const int pidx = (pb0 + 2 * b) * 32 + j;
+        y2a[b] = (pidx < TH * TW ? pidx : TH * TW - 1) * Y_PITCH + hh * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pe = (pb0 + 2 * b) * 32 + ep_px + 8 * i, pr = pe >> 4, pc = pe & 15;      // (TW == 16)
+            const bool ok = b < nb2 && pe < TH * TW && h0 + pr < p.H && w0 + pc < p.W;
+            const long gp = ((long)img * p.H + h0 + pr) * p.W + w0 + pc;
+            xpix[b][i] = ok ? (unsigned)(gp * p.in_pitch + cb * 32 + ep_q * 4) * 4u : kOOB;
+            opix[b][i] = ok ? (unsigned)(gp * p.out_pitch + cb * 32 + ep_q * 4) * 4u : kOOB;
+        }
     }
+    static_assert(TW == 16 && (PB1 + 1) / 2 <= 4 && (PB2 + 1) / 2 <= 3, "pixel index -> (row, column) by shifts; blocks per wave");
     auto y2_frags = [&](int n, AFrag (&f)[3]) {          // chunk n (16 channels of y2)
 #pragma unroll
         for (int b = 0; b < 3; ++b)
@@ -376,13 +404,13 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
         for (int b = 0; b < 3; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
-        const unsigned chb = (unsigned)(q * 64 + ch16) * 4u;            // byte offset of this lane's 16 channels inside a pixel
+        const unsigned chq = (unsigned)(q * 64) * 4u;                    // byte offset of the slice inside a pixel
         w_load(s3base + 2 * q + 2, wf[2]);                               // (the weights first: in-order returns - they are needed first)
         float4 res[3][4];                                                // the residual of this slice: requested before the MFMAs
 #pragma unroll
         for (int b = 0; b < 3; ++b)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) res[b][v] = bload4(rs_x, (xpix[b] != kOOB && !(p.dbg & 2)) ? xpix[b] + chb + 16u * v : kOOB);
+            for (int i = 0; i < 4; ++i) res[b][i] = bload4(rs_x, (xpix[b][i] != kOOB && !(p.dbg & 2)) ? xpix[b][i] + chq : kOOB);
         y2_frags(0, af[0]);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -393,31 +421,38 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
                 if (b < nb2) mfma3(acc[b], wf[n >> 1].h[n & 1], wf[n >> 1].l[n & 1], af[n & 1][b].h, af[n & 1][b].l);
             __builtin_amdgcn_sched_barrier(0);
         }
-        float sv[16], bv[16];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float4 s4 = *reinterpret_cast<const float4 *>(p.bn + 256 + q * 64 + ch16 + 4 * v);
-            const float4 b4 = *reinterpret_cast<const float4 *>(p.bn + 256 + p.Cout + q * 64 + ch16 + 4 * v);
-            sv[4 * v] = s4.x * sc3; sv[4 * v + 1] = s4.y * sc3; sv[4 * v + 2] = s4.z * sc3; sv[4 * v + 3] = s4.w * sc3;
-            bv[4 * v] = b4.x; bv[4 * v + 1] = b4.y; bv[4 * v + 2] = b4.z; bv[4 * v + 3] = b4.w;
-        }
+        const float4 s4 = *reinterpret_cast<const float4 *>(p.bn + 256 + q * 64 + cb * 32 + ep_q * 4);
+        const float4 b4 = *reinterpret_cast<const float4 *>(p.bn + 256 + p.Cout + q * 64 + cb * 32 + ep_q * 4);
+        const float4 sv = make_float4(s4.x * sc3, s4.y * sc3, s4.z * sc3, s4.w * sc3);
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
             if (b >= nb2) continue;
-            float m4 = 0.f;
+            // accumulators -> patch: row j, channels 16 hh + 4 v .. + 3 (only this wave touches its patch: in-order LDS + the waits)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 chk = fmaf(acc[b][4 * v], 0.f, fmaf(acc[b][4 * v + 1], 0.f, fmaf(acc[b][4 * v + 2], 0.f, fmaf(acc[b][4 * v + 3], 0.f, chk))));
-                const float o0 = prelu(fmaf(acc[b][4 * v], sv[4 * v], bv[4 * v] + res[b][v].x), p.slope);
-                const float o1 = prelu(fmaf(acc[b][4 * v + 1], sv[4 * v + 1], bv[4 * v + 1] + res[b][v].y), p.slope);
-                const float o2 = prelu(fmaf(acc[b][4 * v + 2], sv[4 * v + 2], bv[4 * v + 2] + res[b][v].z), p.slope);
-                const float o3 = prelu(fmaf(acc[b][4 * v + 3], sv[4 * v + 3], bv[4 * v + 3] + res[b][v].w), p.slope);
-                m4 = fmaxf(fmaxf(m4, fmaxf(fabsf(o0), fabsf(o1))), fmaxf(fabsf(o2), fabsf(o3)));
+                *reinterpret_cast<float4 *>(patch + j * P_PITCH + (16 * hh + 4 * v) * 4) =
+                    make_float4(acc[b][4 * v], acc[b][4 * v + 1], acc[b][4 * v + 2], acc[b][4 * v + 3]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float4 t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const float4 *>(patch + (ep_px + 8 * i) * P_PITCH + ep_q * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (read before the next block overwrites the patch)
+            float m4 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float o0 = prelu(fmaf(t[i].x, sv.x, b4.x + res[b][i].x), p.slope);
+                const float o1 = prelu(fmaf(t[i].y, sv.y, b4.y + res[b][i].y), p.slope);
+                const float o2 = prelu(fmaf(t[i].z, sv.z, b4.z + res[b][i].z), p.slope);
+                const float o3 = prelu(fmaf(t[i].w, sv.w, b4.w + res[b][i].w), p.slope);
+                const float m = fmaxf(fmaxf(fabsf(o0), fabsf(o1)), fmaxf(fabsf(o2), fabsf(o3)));
+                m4 = fmaxf(m4, opix[b][i] != kOOB ? m : 0.f);
                 u32x4 o;
                 o.x = __float_as_uint(o0); o.y = __float_as_uint(o1); o.z = __float_as_uint(o2); o.w = __float_as_uint(o3);
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, opix[b] != kOOB ? opix[b] + chb + 16u * v : kOOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, opix[b][i] != kOOB ? opix[b][i] + chq : kOOB, 0, 0);
             }
-            amax = fmaxf(amax, opix[b] != kOOB ? m4 : 0.f);
+            amax = fmaxf(amax, m4);
         }
         wf[1] = wf[0];
         wf[0] = wf[2];
@@ -446,6 +481,20 @@ extern "C" int tsod_bottleneck_fp16x2(const tsod_bottleneck_desc *d, const float
     Params p;
     p.x = x; p.out = out; p.wstream = static_cast<const unsigned char *>(wstream); p.bn = bn;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_pitch = d->in_pitch; p.Cout = d->Cout; p.out_pitch = d->out_pitch;
+    // tile height: rounds of the launch (two workgroups per CU) x MFMAs the slowest wave issues per tile
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        (void)hipGetLastError();
+        cus = 256;
+    }
+    auto cost = [&](int th, int mfma_slowest) {
+        const int64_t tiles = (int64_t)d->N * ((d->W + TW - 1) / TW) * ((d->H + th - 1) / th);
+        return (double)((tiles + 2 * cus - 1) / (2 * cus)) * mfma_slowest;
+    };
+    const int n1 = d->Cin / 32, nq = d->Cout / 64;
+    static const int force_th = [] { const char *e = getenv("TSOD_BN_TH"); return e ? atoi(e) : 0; }();
+    const int TH = force_th == 8 || force_th == 10 ? force_th
+                   : (cost(8, 3 * (3 * 2 * n1 + 2 * 36 + 2 * 4 * nq)) < cost(10, 3 * (4 * 2 * n1 + 3 * 36 + 3 * 4 * nq)) ? 8 : 10);
     p.tiles_x = (d->W + TW - 1) / TW; p.tiles_y = (d->H + TH - 1) / TH;
     TSOD_REQUIRE((uint64_t)d->N * d->H * d->W * d->out_pitch * 4 < 0xFFFFFFF0ull && d->Cin % 64 == 0, TSOD_ERR_UNSUPPORTED);
     p.x_bytes = (unsigned)((uint64_t)d->N * d->H * d->W * d->in_pitch * 4);
@@ -457,6 +506,7 @@ extern "C" int tsod_bottleneck_fp16x2(const tsod_bottleneck_desc *d, const float
     p.dbg = dbg;
     const int64_t grid = (int64_t)d->N * p.tiles_x * p.tiles_y;
     TSOD_REQUIRE(grid < 0x7FFFFFFF, TSOD_ERR_UNSUPPORTED);
-    hipLaunchKernelGGL(bottleneck_kernel, dim3((unsigned)grid), dim3(256), 0, tsod_stream(stream), p);
+    if (TH == 8) hipLaunchKernelGGL(bottleneck_kernel<8>, dim3((unsigned)grid), dim3(256), 0, tsod_stream(stream), p);
+    else hipLaunchKernelGGL(bottleneck_kernel<10>, dim3((unsigned)grid), dim3(256), 0, tsod_stream(stream), p);
     return tsod_launch_status();
 }
