@@ -77,13 +77,13 @@ struct Params {
 
 __device__ __forceinline__ float prelu(float v, float a) { return fmaxf(v, 0.f) + a * fminf(v, 0.f); }
 
-// two fp16 pieces of s * x for a pair of elements (the same bits as split2_pair of conv_igemm_f32.hip)
+// two fp16 pieces of s * x for a pair of elements (split2_pair of conv_igemm_f32.hip: four mixed-precision FMAs; `sc` wave-uniform)
 __device__ __forceinline__ void split2(float x0, float x1, float sc, unsigned &h, unsigned &l) {
-    const float a0 = sc * x0, a1 = sc * x1;
-    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
-    const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
-    h = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-    l = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h), "=&v"(l) : "v"(x0), "v"(x1), "s"(sc));
 }
 
 // three piece products, smallest first: lo*hi, hi*lo, hi*hi

@@ -138,14 +138,17 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &h, uns
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
-// fp16x2 (TSOD_PREC_FP16X2): two elements as fp16 pieces of sc * x: hi = rne(sc x), lo = rne(sc x - hi) (the subtraction is exact);
-// the plain-code form of the split (the asm statements of conv_dma_kernel's loop compute the same bits)
+// fp16x2 (TSOD_PREC_FP16X2): two elements as fp16 pieces of sc * x: hi = rne_f16(sc x), lo = rne_f16(sc x - hi) (the product by a
+// power of two and the subtraction are exact in f32, so each piece is ONE rounding of an exact value).  Four instructions per pair
+// on the mixed-precision FMA (v_fma_mixlo/mixhi_f16: f32 x f32 + f16 -> f16, written into one half of the destination): no separate
+// scale multiply, no conversion of hi back to f32, no pack - the form with v_cvt_pk_f16_f32 / v_cvt_f32_f16 / v_sub_f32 took eight,
+// and the split is what the fp16x2 K loops are short of issue slots for (both kernel families; `sc` wave-uniform).
 __device__ __forceinline__ void split2_pair(float x0, float x1, float sc, unsigned &h, unsigned &l) {
-    const float xs0 = sc * x0, xs1 = sc * x1;
-    const _Float16 h0 = (_Float16)xs0, h1 = (_Float16)xs1;
-    const _Float16 l0 = (_Float16)(xs0 - (float)h0), l1 = (_Float16)(xs1 - (float)h1);
-    h = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-    l = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h), "=&v"(l) : "v"(x0), "v"(x1), "s"(sc));
 }
 
 // channel index inside the (concatenated) Cin -> offset inside the input pixel (select chain, no branches)
@@ -1066,8 +1069,9 @@ __device__ __forceinline__ void gap_read(f32x16 &c, const bf16x8 &a, const bf16x
 // ---- "fp16x2" (TSOD_PREC_FP16X2): every operand as TWO fp16 pieces of s * x (hi = rne(s x), lo = rne(s x - hi), s a power of two
 // per tensor), THREE piece products per f32 product (lo*hi, hi*lo, hi*hi; the dropped lo*lo is 2^-22) on
 // v_mfma_f32_32x32x16_f16, f32 accumulation: the f32 kernel's accuracy with half the MFMAs of bf16x3 while |s x| < 65504.
-//   gap2_a:  MFMA; xs = s * x (two elements); h = rne_f16x2(xs); t = f32(h)
-//   gap2_b:  MFMA; r = xs - t (exact); l = rne_f16x2(r); one LDS fragment read of the next stage
+//   gap2_a:  MFMA; h = rne_f16x2(s * x) for two elements (v_fma_mixlo / mixhi_f16: the product by a power of two is exact)
+//   gap2_b:  MFMA; l = rne_f16x2(s * x - h) (the same instructions with h as the f16 addend: exact before the one rounding); one
+//            LDS fragment read of the next stage
 __device__ __forceinline__ void mfma_f16(f32x16 &c, const bf16x8 &a, const bf16x8 &b) {
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
@@ -1077,25 +1081,20 @@ __device__ __forceinline__ void gap2_read(f32x16 &c, const bf16x8 &a, const bf16
                  "ds_read_b128 %1, %4 offset:%5"
                  : "+v"(c), "=&v"(rd) : "v"(a), "v"(b), "v"(addr), "n"(OFF) : "memory");
 }
-__device__ __forceinline__ void gap2_a(f32x16 &c, const bf16x8 &a, const bf16x8 &b, float x0, float x1, float sc, float &xs0, float &xs1,
-                                       unsigned &h, float &t0, float &t1) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %6, %7, %0\n\t"
-                 "v_mul_f32 %1, %10, %8\n\t"
-                 "v_mul_f32 %2, %10, %9\n\t"
-                 "v_cvt_pk_f16_f32 %3, %1, %2\n\t"
-                 "v_cvt_f32_f16 %4, %3\n\t"
-                 "v_cvt_f32_f16_sdwa %5, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
-                 : "+v"(c), "=&v"(xs0), "=&v"(xs1), "=&v"(h), "=&v"(t0), "=&v"(t1) : "v"(a), "v"(b), "v"(x0), "v"(x1), "s"(sc));
+__device__ __forceinline__ void gap2_a(f32x16 &c, const bf16x8 &a, const bf16x8 &b, float x0, float x1, float sc, unsigned &h) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, %0\n\t"
+                 "v_fma_mixlo_f16 %1, %4, %6, 0\n\t"
+                 "v_fma_mixhi_f16 %1, %5, %6, 0"
+                 : "+v"(c), "=&v"(h) : "v"(a), "v"(b), "v"(x0), "v"(x1), "s"(sc));
 }
 template <int OFF, typename T>
-__device__ __forceinline__ void gap2_b(f32x16 &c, const bf16x8 &a, const bf16x8 &b, float xs0, float xs1, float t0, float t1, float &r0, float &r1,
-                                       unsigned &l, T &rd, unsigned addr) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %5, %6, %0\n\t"
-                 "v_sub_f32 %1, %7, %9\n\t"
-                 "v_sub_f32 %2, %8, %10\n\t"
-                 "v_cvt_pk_f16_f32 %3, %1, %2\n\t"
-                 "ds_read_b128 %4, %11 offset:%12"
-                 : "+v"(c), "=&v"(r0), "=&v"(r1), "=&v"(l), "=&v"(rd) : "v"(a), "v"(b), "v"(xs0), "v"(xs1), "v"(t0), "v"(t1), "v"(addr), "n"(OFF) : "memory");
+__device__ __forceinline__ void gap2_b(f32x16 &c, const bf16x8 &a, const bf16x8 &b, float x0, float x1, float sc, unsigned h, unsigned &l,
+                                       T &rd, unsigned addr) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %3, %4, %0\n\t"
+                 "v_fma_mixlo_f16 %1, %5, %7, -%8 op_sel_hi:[0,0,1]\n\t"
+                 "v_fma_mixhi_f16 %1, %6, %7, -%8 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                 "ds_read_b128 %2, %9 offset:%10"
+                 : "+v"(c), "=&v"(l), "=&v"(rd) : "v"(a), "v"(b), "v"(x0), "v"(x1), "s"(sc), "v"(h), "v"(addr), "n"(OFF) : "memory");
 }
 #ifdef TSOD_DIAG_MFMA16
 // timing probe only (make mfma16; wrong results by design): every v_mfma_f32_32x32x16_bf16 of the K loop replaced by TWO
@@ -1435,7 +1434,6 @@ conv_dma_kernel(const ConvParams p) {
 #define TSOD_DMA2(I) do { if constexpr ((I) < P) issue_piece(std::integral_constant<int, (I)>{}, std::integral_constant<bool, TABLE>{}, slot_off); } while (0)
 #define TSOD_MF2(n) acc[0][(n) & 3], cur.a[PA[(n) >> 2]], cur.b[(n) & 3][PB[(n) >> 2]]
         static_assert(NPL != 2 || P <= 5, "DMA slots of an fp16x2 phase");
-        float xs0, xs1;
         if constexpr (TABLE) {
             lds_read16<0>(t_e, tab_ptr);
             tab_ptr += 16;
@@ -1465,8 +1463,8 @@ conv_dma_kernel(const ConvParams p) {
             wait_lgkm<4>();
         }
 #define TSOD_SPLIT2(N0, X0, X1, G)                                                                        \
-        gap2_a(TSOD_MF2(N0), X0, X1, a_scale_s, xs0, xs1, hh[G], t0, t1);                                  \
-        gap2_b<B_PLANE>(TSOD_MF2(N0 + 1), xs0, xs1, t0, t1, r0, r1, ll[G], nxt.b[G][1], b_addr[G] + soff); \
+        gap2_a(TSOD_MF2(N0), X0, X1, a_scale_s, hh[G]);                                                    \
+        gap2_b<B_PLANE>(TSOD_MF2(N0 + 1), X0, X1, a_scale_s, hh[G], ll[G], nxt.b[G][1], b_addr[G] + soff); \
         TSOD_DMA2(1 + G);
         TSOD_SPLIT2(4, raw0.x, raw0.y, 0)
         TSOD_SPLIT2(6, raw0.z, raw0.w, 1)
