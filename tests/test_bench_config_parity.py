@@ -463,7 +463,8 @@ def test_config3_batch16_in_the_form_bench_times(dev):
     xg = x.to(dev)
     with torch.inference_mode():
         table = model.tune(xg, precisions=(0, 1, 2), in_flight=2, reps=2)
-        assert set(table) == {"serial", "in_flight", "heads"} and len(table["serial"]) == 49
+        assert set(table) == {"serial", "in_flight", "heads", "fuse_bottleneck"}
+        assert len(table["serial"]) == len(table["in_flight"]) == (43 if table["fuse_bottleneck"] else 49)
         n_h2 = sum(1 for r in table["serial"] if r[3] == 2)
         for sched, depth in (("serial", 1), ("in_flight", 2)):
             server = InFlightDetector(model, xg, depth=depth, tiles=table)
@@ -473,7 +474,7 @@ def test_config3_batch16_in_the_form_bench_times(dev):
                 outs = [o.cpu() for o in server.result(t)]
             server.drain()
             worst = _check_images(outs[:4], sd, x, "resnet50", (0, 7, 15), max_pos=6)
-            print("config 3 as benched:", sched, "fp16x2 layers", n_h2, worst)
+            print("config 3 as benched:", sched, "fp16x2 layers", n_h2, "one-launch bottlenecks:", table["fuse_bottleneck"], worst)
     assert n_h2 >= 20, table["serial"]
 
 
