@@ -790,11 +790,15 @@ def test_dma_conv_tiles_at_full_layer_sizes(ops, dev, shape):
     ref = ops.conv2d_nhwc(x, w, pad=k // 2, tile=3, split_k=1)                       # f32 MFMA, whole tiles
     tol = 3e-6 * math.sqrt(Cin * k * k) * 2 + 2e-5
     for tile in DMA_TILE_IDS:
+        prec = 2 if tile == 23 else 1                    # (d192x128 exists in fp16x2 only)
         for split in (1, -1, -2, 3):
-            y = ops.conv2d_nhwc(x, w, pad=k // 2, tile=tile, split_k=split, precision=1)
+            y = ops.conv2d_nhwc(x, w, pad=k // 2, tile=tile, split_k=split, precision=prec)
             assert (y - ref).abs().max().item() <= tol, (tile, split)
-            y4 = ops.conv2d_nhwc(x * 4.0, w, pad=k // 2, tile=tile, split_k=split, precision=1)
-            assert torch.equal(y4, y * 4.0), (tile, split, "linearity in 4 must be exact")
+            y4 = ops.conv2d_nhwc(x * 4.0, w, pad=k // 2, tile=tile, split_k=split, precision=prec)
+            if prec == 1:
+                assert torch.equal(y4, y * 4.0), (tile, split, "linearity in 4 must be exact")
+            else:       # fp16x2 at a static exponent: the low pieces of small elements sit in fp16's subnormals, where 4 x rounds differently
+                assert (y4 - y * 4.0).abs().max().item() <= 4 * tol, (tile, split)
     z = ops.conv2d_nhwc(torch.zeros_like(x), w, pad=k // 2, tile=DMA_TILE_IDS[0], split_k=-2, precision=1)
     assert torch.count_nonzero(z).item() == 0
 

@@ -1131,6 +1131,11 @@ __device__ __forceinline__ void gap_read(Acc16 &c, const bf16x8 &a, const bf16x8
 #endif
 
 constexpr int dma_stage_bytes(int bm, int bk, int bn = 128, int npl = 3) { return bm * bk * 4 + npl * bn * bk * 2; }
+// workgroups of an LDS-DMA tile per CU: two where two rings fit the LDS AND two workgroups' waves stay at two per SIMD (the loop
+// holds ~214 registers: a third wave on a SIMD does not fit)
+constexpr int dma_wgs_per_cu(int bm, int bk, int waves_k, int s, int waves_n, int npl) {
+    return (2 * s * dma_stage_bytes(bm, bk, 128 * waves_n, npl) <= 160 * 1024 && 2 * (bm / 32) * waves_k * waves_n <= 8) ? 2 : 1;
+}
 constexpr int kDmaTabEntries = 640;   // K-steps of one workgroup's K range + ring depth + 1 (tile_ok_for keeps K / bk + 8 below it)
 constexpr unsigned kDmaSecondBit = 0x80000000u;   // validity-mask bit of the second source's 1x1 tap (filter taps use bits 0..30)
 
@@ -1138,7 +1143,7 @@ constexpr unsigned kDmaSecondBit = 0x80000000u;   // validity-mask bit of the se
 // channels: more FLOP per byte fetched from beyond the CU (the activation stage is shared) at the same 128-row granularity
 // NPL = pieces per operand: 3 = bf16x3 (six piece products per k chunk), 2 = fp16x2 (three)
 template <int BM, int BK, int WAVES_K, int S, bool BALANCED, int WAVES_N = 1, int NPL = 3>
-__global__ void __launch_bounds__((BM / 32) * WAVES_K * WAVES_N * 64, (2 * S * dma_stage_bytes(BM, BK, 128 * WAVES_N, NPL) <= 160 * 1024) ? 2 : 1)
+__global__ void __launch_bounds__((BM / 32) * WAVES_K * WAVES_N * 64, dma_wgs_per_cu(BM, BK, WAVES_K, S, WAVES_N, NPL))
 conv_dma_kernel(const ConvParams p) {
     constexpr int BN = 128 * WAVES_N, TN = 4, WAVES_M = BM / 32, WAVES = WAVES_M * WAVES_K * WAVES_N, THREADS = WAVES * 64;
     static_assert(BK == 16 * WAVES_K, "every wave owns one 16-k chunk of the stage");
@@ -1165,7 +1170,7 @@ conv_dma_kernel(const ConvParams p) {
     // ds_read_b128 per phase and a few vector operations on its result cost next to nothing (they issue in MFMA shadows).
     // Tiles whose ring fills the LDS of two workgroups per CU keep the scalar form (TABLE false).
     constexpr int TAB_N = kDmaTabEntries, TAB_BYTES = TAB_N * 16, TAB_OFF = S * STAGE + (B_PAD ? 1024 : 0);
-    constexpr int LB_WGS = (2 * S * dma_stage_bytes(BM, BK, 128 * WAVES_N, NPL) <= 160 * 1024) ? 2 : 1;
+    constexpr int LB_WGS = dma_wgs_per_cu(BM, BK, WAVES_K, S, WAVES_N, NPL);
     constexpr bool TABLE = LB_WGS * (TAB_OFF + TAB_BYTES) <= 160 * 1024;
     // fp16x2: 2 x 256 bytes behind the table for the range words of the two sources (the bf16x3 d128x128 ring fills the LDS of two
     // workgroups per CU exactly and has no use for them)
@@ -1838,13 +1843,14 @@ const TileInfo kTiles[TSOD_TILE_COUNT] = {
     {64, 64, 64, 8, 1.40f, 32, 1, 0},   {128, 64, 128, 4, 1.35f, 32, 1, 0}, {128, 64, 256, 4, 1.12f, 32, 1, 1}, {64, 128, 256, 4, 1.12f, 32, 1, 1},
     {128, 128, 256, 2, 1.02f, 32, 1, 1},
     {128, 128, 256, 2, 0.80f, 16, 4, 1, 1}, {64, 128, 256, 1, 0.95f, 32, 3, 1, 1}, {256, 128, 512, 1, 0.72f, 16, 4, 1, 1},
-    {64, 128, 256, 2, 0.98f, 32, 2, 1, 1}, {128, 256, 512, 1, 0.74f, 16, 4, 1, 1}, {128, 128, 512, 1, 0.70f, 32, 3, 1, 1}};
+    {64, 128, 256, 2, 0.98f, 32, 2, 1, 1}, {128, 256, 512, 1, 0.74f, 16, 4, 1, 1}, {128, 128, 512, 1, 0.70f, 32, 3, 1, 1},
+    {192, 128, 384, 1, 0.74f, 16, 4, 1, 1}};
 // bf16x3 = 1: the tile also exists as a bf16x3 variant (three bf16 planes per operand fit the 64 KB of static LDS)
 
 // workgroups per CU: the f32 figure (VGPR / LDS bound), for bf16x3 additionally capped by its larger LDS footprint
 // tiles that exist in the fp16x2 arithmetic: the register-staged bf16x3 tiles and d128x128k32
 bool fp16x2_tile(int t) {   // (the 64-row LDS-DMA tiles would need six DMA slots in a 12-MFMA phase: not built)
-    return t == TSOD_TILE_D128x128_K32 || t == TSOD_TILE_D128x128 || t == TSOD_TILE_D256x128 || t == TSOD_TILE_D128x256 ||
+    return t == TSOD_TILE_D128x128_K32 || t == TSOD_TILE_D128x128 || t == TSOD_TILE_D256x128 || t == TSOD_TILE_D128x256 || t == TSOD_TILE_D192x128 ||
            (kTiles[t].bf16x3 && !kTiles[t].dma);
 }
 
@@ -1875,6 +1881,7 @@ int validate(const tsod_conv2d_desc *d) {
     TSOD_REQUIRE(d->tile >= 0 && d->tile < TSOD_TILE_COUNT && d->split_k >= -2 && d->split_k <= 64, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->precision == TSOD_PREC_BF16X3 || d->precision == TSOD_PREC_FP16X2, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->tile == TSOD_TILE_AUTO || kTiles[d->tile].bf16x3, TSOD_ERR_UNSUPPORTED);
+    TSOD_REQUIRE(d->tile != TSOD_TILE_D192x128 || d->precision == TSOD_PREC_FP16X2, TSOD_ERR_UNSUPPORTED);   // (fp16x2 only)
     TSOD_REQUIRE(d->precision != TSOD_PREC_F32 || d->tile == TSOD_TILE_AUTO || !kTiles[d->tile].dma, TSOD_ERR_UNSUPPORTED);
     if (d->precision == TSOD_PREC_FP16X2) {                       // (the register-staged bf16x3 tiles and the 128x128 / 32-k LDS-DMA tile)
         TSOD_REQUIRE(d->tile == TSOD_TILE_AUTO || fp16x2_tile(d->tile), TSOD_ERR_UNSUPPORTED);
@@ -2053,6 +2060,7 @@ Sched resolve(const tsod_conv2d_desc *d) {
         if (d->tile != TSOD_TILE_AUTO && d->tile != t) continue;
         if (d->precision && !kTiles[t].bf16x3) continue;
         if (!d->precision && kTiles[t].dma) continue;
+        if (t == TSOD_TILE_D192x128 && d->precision != TSOD_PREC_FP16X2) continue;
         if (d->precision == TSOD_PREC_FP16X2 && !fp16x2_tile(t)) continue;
         if (!tile_ok_for(d, t)) continue;        // (also an explicitly named tile: the caller gets TSOD_ERR_UNSUPPORTED)
         if (d->split_k != 0) {
@@ -2208,6 +2216,7 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
             case TSOD_TILE_D128x128: launch_dma_tile<128, 16, 1, 4, 1, 2>(p, sc.grid, s); break;
             case TSOD_TILE_D256x128: launch_dma_tile<256, 16, 1, 4, 1, 2>(p, sc.grid, s); break;
             case TSOD_TILE_D128x256: launch_dma_tile<128, 16, 1, 4, 2, 2>(p, sc.grid, s); break;
+            case TSOD_TILE_D192x128: launch_dma_tile<192, 16, 1, 4, 1, 2>(p, sc.grid, s); break;
             default: launch_tile<64, 64, 32, 32, 2, 2, 32, 2>(p, sc.grid, s); break;      // TSOD_TILE_64x64 (two LDS stages)
         }
         return tsod_launch_status();
