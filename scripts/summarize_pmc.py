@@ -14,12 +14,19 @@ def short(n):
     return m.group(1) if m else n[:60]
 
 
+def is_gemm(k):
+    """the matrix launches of a forward: both conv kernel families and the one-launch bottleneck"""
+    return 'conv_igemm' in k or 'conv_dma' in k or 'bottleneck_kernel' in k
+
+
 def arith(k):
     """The arithmetic is the template's LAST argument in both kernel families:
     conv_igemm_kernel<BM, BN, WM, WN, MINW, NBUF, BK, PREC> (8 arguments; fewer = the defaults = f32): PREC 0 f32, 1 bf16x3, 2 fp16x2;
     conv_dma_kernel<BM, BK, WAVES_K, S, BALANCED, WAVES_N, NPL> (7 arguments): NPL 3 = bf16x3, 2 = fp16x2."""
     m = re.search(r'<([^>]*)>', k)
     args = m.group(1).replace(' ', '').split(',') if m else []
+    if 'bottleneck_kernel' in k:
+        return 'fp16x2 (one-launch bottleneck)'
     if 'conv_dma' in k:
         return {'2': 'fp16x2 (LDS-DMA)', '3': 'bf16x3 (LDS-DMA)'}.get(args[-1] if len(args) == 7 else '3', 'bf16x3 (LDS-DMA)')
     if len(args) == 8:
@@ -53,8 +60,8 @@ print(f"# {label} - PMC counters, `bench.py --no-graph --in-flight 1` ({A.worklo
 print("Per dispatch, averaged over the dispatches of the second half of the forwards (the timed steps; the first half contains plan")
 print("building and warm-up; kernels that only ran before that - tuning candidates - are not listed).  `FETCH_SIZE` / `WRITE_SIZE` are KiB; on gfx950 `FETCH_SIZE` under-reports wide")
 print("coalesced reads by 2x (MI355X_MICROARCH.md, HBM section), so HBM read bytes = 2 x FETCH_SIZE.  Commands: profiles/README.md.\n")
-g = [c.get('GRBM_GUI_ACTIVE') for k in fe if ('conv_igemm' in k or 'conv_dma' in k) for _, c in fe[k].items() if c.get('GRBM_GUI_ACTIVE')]
-d = [dfe[i] for k in fe if ('conv_igemm' in k or 'conv_dma' in k) for i, c in fe[k].items() if c.get('GRBM_GUI_ACTIVE')]
+g = [c.get('GRBM_GUI_ACTIVE') for k in fe if is_gemm(k) for _, c in fe[k].items() if c.get('GRBM_GUI_ACTIVE')]
+d = [dfe[i] for k in fe if is_gemm(k) for i, c in fe[k].items() if c.get('GRBM_GUI_ACTIVE')]
 clock_meas = sum(g) / 8 / (sum(d) * 1e-6) if d else 2.4e9
 clock = min(clock_meas, 2.4e9)
 print("## Matrix-core utilisation of the conv GEMMs (pass 1: SQ counters)\n")
@@ -80,7 +87,7 @@ def timed_only(per, items):
 
 
 for k in sorted(sq):
-    if 'conv_igemm' not in k and 'conv_dma' not in k:
+    if not is_gemm(k):
         continue
     ds = timed_only(sq, list(sq[k].items()))
     n = len(ds)
@@ -127,7 +134,7 @@ def last_forward(per):
     start = max(int(i) for k in per if 'nchw_to_nhwc' in k for i in per[k])
     out = collections.defaultdict(lambda: [0, 0.0])
     for k in per:
-        fam = 'conv_igemm_kernel + conv_dma_kernel' if ('conv_igemm' in k or 'conv_dma' in k) else k
+        fam = 'conv_igemm_kernel + conv_dma_kernel' if is_gemm(k) else k
         for i, c in per[k].items():
             if int(i) >= start:
                 out[fam][0] += 1
@@ -143,7 +150,7 @@ fam = 'conv_igemm_kernel + conv_dma_kernel'
 if fam in lf:
     mb = (2 * lf[fam][1] + lw[fam][1]) * 1024 / 1e6
     print(f"| `{fam}` | {lf[fam][0]} | {lf[fam][1]:.0f} | {lw[fam][1]:.0f} | {mb:.1f} |")
-    print(f"\n{mb / 1e3:.2f} GB per forward over all {lf[fam][0]} GEMM launches (53 trunk convs + fused RPN conv + fused head GEMM; K-slice slabs")
+    print(f"\n{mb / 1e3:.2f} GB per forward over all {lf[fam][0]} matrix launches (the trunk's convs and one-launch bottlenecks + fused RPN conv + fused head GEMM; K-slice slabs")
     print("are written and read inside these launches now, there is no reduce kernel).  The excess over the algorithmic bytes is")
     print("(a) the K-slice partial slabs (write-through stores, read back by the tile's last-arriving slice), (b) the activation")
     print("tile re-read by every output-channel tile of its row block once it has left the XCD's L2, (c) the 7x8x4 stem reading its")
@@ -154,7 +161,7 @@ def last_forward_convs(per, dur):
     """[(dispatch id, kernel, counters, us)] of the conv GEMMs of the last forward, in launch order"""
     st = forward_starts(per)
     lo = st[-1]
-    rows = [(int(i), k, c, dur[i]) for k in per if ('conv_igemm' in k or 'conv_dma' in k) for i, c in per[k].items() if int(i) >= lo]
+    rows = [(int(i), k, c, dur[i]) for k in per if is_gemm(k) for i, c in per[k].items() if int(i) >= lo]
     return sorted(rows)
 
 
