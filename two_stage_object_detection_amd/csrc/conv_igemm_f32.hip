@@ -1212,17 +1212,25 @@ conv_dma_kernel(const ConvParams p) {
             }
         }
     }
+  // Balanced schedule: the segments of the range [g, g_end) are taken LAST FIRST.  A workgroup's range is about one K sweep long and
+  // starts somewhere inside a tile: in sequence order it would run that tile's K tail and then the next tile's K head, every
+  // workgroup at another K position at any moment - a weight block wanted by one is in nobody's L2 (measured at batch 8:
+  // layer4's 3x3 convs moved 802 MB for 43.8 MB of operands, L2 hit rate 17 %, and ran at 5.8 TB/s: bound by their own
+  // re-fetches).  Head first, tail second, the K position of EVERY workgroup is close to the time since launch: the workgroups
+  // of an XCD sweep K together and share each weight block as it passes, as whole tiles in lock-step do.  Segments are independent
+  // (own accumulators, own slab): the order changes no result.
   for (; g < g_end;) {
     int tile_id, kt_begin, kt_end;
     SliceMap sm;
     if (balanced) {
-        tile_id = (int)(g / p.ksteps);
+        tile_id = (int)((g_end - 1) / p.ksteps);
         const long tile_k0 = (long)tile_id * p.ksteps;
-        kt_begin = (int)(g - tile_k0);
-        kt_end = (int)min((long)p.ksteps, kt_begin + (g_end - g));
+        const long seg_lo = g > tile_k0 ? g : tile_k0;
+        kt_begin = (int)(seg_lo - tile_k0);
+        kt_end = (int)(g_end - tile_k0);
         const int first = (int)(tile_k0 / p.sk_q), last = (int)((tile_k0 + p.ksteps - 1) / p.sk_q);
         sm = {first == last ? -1 : (int)blockIdx.x - first, last - first + 1, tile_id, first, (long)p.sk_q, tile_k0};
-        g += kt_end - kt_begin;
+        g_end = seg_lo;
     } else {
         int z;
         work_item(p, tile_id, z);
