@@ -45,6 +45,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kPatchLD = 36;  // row pitch (floats) of the epilogue transpose patches
+constexpr int kChanTab = 512; // entries of the register-staged kernel's channel-offset table (1x1 convs over concatenated segments: K <= 2048)
 
 struct ConvParams {
     const float *in, *w, *scale, *shift, *res;
@@ -81,6 +82,9 @@ struct ConvParams {
     const float *in2;
     unsigned in2_bytes;
     int K1, c2, in2_pitch, in2_off, stride2, H2, W2;
+    int pointwise_tab;            // 1: a 1x1 filter (no padding, no second source) over several channel segments (HarDNet's concatenated
+                                  //    inputs) with K <= 4 * kChanTab: the channel offset of every 4-k chunk comes from a table the workgroup
+                                  //    builds in LDS once, instead of a select chain over the segments + the k -> (tap, channel) arithmetic
     int uniform_tap;              // 1: Cin % K-step == 0 and one channel segment: a K-step lies inside ONE filter tap and one
                                   //    contiguous channel run, so (kh, kw, channel base) are wave-uniform and live on the scalar unit
     float neg_slope, act_hi;      // activation as min(max(v,0) + neg_slope*min(v,0), act_hi)
@@ -575,6 +579,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
     constexpr int PATCHES = (THREADS / 64) * 32 * kPatchLD;                      // epilogue transpose patches, one per wave
     constexpr int SMEM = NBUF * STAGE > PATCHES ? NBUF * STAGE : PATCHES;
     __shared__ __align__(16) float smem[SMEM];
+    __shared__ int chan_tab[kChanTab];                 // pointwise_tab: byte offset inside the pixel of 4-k chunk j (kOOB past K)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -646,6 +651,10 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
         }
     }
 
+    if (p.pointwise_tab) {           // (wave-uniform; the barrier in front of the K loop's first LDS reads publishes the table)
+        for (int jj = tid; jj < kChanTab; jj += THREADS) chan_tab[jj] = 4 * jj < p.K ? seg_channel(p, 4 * jj) * 4 : (int)kOOB;
+        __syncthreads();
+    }
     int kq = kt_begin;               // K-step being loaded
     int k = kt_begin * kBK + c4;     // this thread's k for the A chunk of that K-step
 
@@ -701,12 +710,20 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
             return;
         }
         // k -> (filter tap, channel) without divisions or loops: exact for k < 2^21
-        const int seg = (int)(((float)k + 0.5f) * p.inv_cin);
-        const int ci = k - seg * p.Cin;
-        const int kh = (int)(((float)seg + 0.5f) * p.inv_kw);
-        const int kw = seg - kh * p.KW;
-        const bool kin = k < p.K;
-        const unsigned delta = (unsigned)(((kh * p.W + kw) * p.in_pitch + seg_channel(p, ci)) * 4);
+        int kh = 0, kw = 0;
+        bool kin;
+        unsigned delta;
+        if (p.pointwise_tab) {       // 1x1 over concatenated segments: tap (0, 0); the chunk's channel offset is one LDS word (kOOB past K)
+            delta = (unsigned)chan_tab[k >> 2];
+            kin = delta != kOOB;
+        } else {
+            const int seg = (int)(((float)k + 0.5f) * p.inv_cin);
+            const int ci = k - seg * p.Cin;
+            kh = (int)(((float)seg + 0.5f) * p.inv_kw);
+            kw = seg - kh * p.KW;
+            kin = k < p.K;
+            delta = (unsigned)(((kh * p.W + kw) * p.in_pitch + seg_channel(p, ci)) * 4);
+        }
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
@@ -2186,6 +2203,9 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
     const Sched sc = resolve(d);
     TSOD_REQUIRE(sc.cost < 1e299, TSOD_ERR_UNSUPPORTED);        // the named tile cannot run this problem (LDS-DMA tiles: tile_ok_for)
     p.uniform_tap = (d->n_seg == 1 && p.Cin % kTiles[sc.tile].bk == 0) ? 1 : 0;
+    static const bool no_chan_tab = getenv("TSOD_NO_CHAN_TAB") != nullptr;     // diagnostic: the arithmetic loader for every layer
+    p.pointwise_tab = (!no_chan_tab && !p.uniform_tap && !kTiles[sc.tile].dma && d->KH == 1 && d->KW == 1 && d->pad_h == 0 && d->pad_w == 0 && d->stride == 1 &&
+                       p.c2 == 0 && p.K <= 4 * kChanTab) ? 1 : 0;
     TSOD_REQUIRE(p.c2 == 0 || (p.uniform_tap && p.K1 % kTiles[sc.tile].bk == 0 && p.c2 % kTiles[sc.tile].bk == 0), TSOD_ERR_UNSUPPORTED);
     p.ksteps = (p.K + kTiles[sc.tile].bk - 1) / kTiles[sc.tile].bk;
     p.tiles_m = sc.tiles_m; p.tiles_n = sc.tiles_n;
