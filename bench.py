@@ -91,6 +91,8 @@ def parse(argv=None):
                     "in its range words (per forward, inside the launches: any finite input range) - all three f32-accurate and "
                     "gated by the same parity suite; auto (default) = the autotuner picks per layer among all three; "
                     "auto-bf16x3 = among f32 and bf16x3 only (rounds 2-3)")
+    ap.add_argument("--fuse-stem", default="auto", choices=("auto", "on", "off"), help="ResNet's conv1 + bn1 + PReLU + max pool (and the "
+                    "NCHW -> NHWC pass) as one launch (tsod_stem_fp16x2): auto = FasterRCNN.tune times the backbone with and without")
     ap.add_argument("--fuse-bottleneck", default="auto", choices=("auto", "on", "off"), help="ResNet layer1's identity bottlenecks as one "
                     "launch each (tsod_bottleneck_fp16x2): auto = FasterRCNN.tune times one pass over the matrix launches with and "
                     "without and keeps the faster structure")
@@ -255,6 +257,11 @@ def dump_layers(plan, path, conv_ms=None, seq_ms=None):
         d = st.desc
         times = {"seq_us": None if seq_ms is None else round(seq_ms[i] * 1e3, 2),          # inside the sequence (the one to quote)
                  "event_us": None if conv_ms is None else round(conv_ms[i] * 1e3, 2)}      # isolated repeats on hot operands
+        if isinstance(st, FusedStep) and st is getattr(plan, "stem_step", None):
+            oh, ow = (d.H - 1) // 2 + 1, (d.W - 1) // 2 + 1
+            rows.append({"name": st.name, "flops": int(st.flops), "algorithmic_bytes": int(st.algorithmic_bytes), "tile": "stem4x16",
+                         "split_k": 1, "precision": 2, "slab_bytes": 0, "M": int(d.N * oh * ow), "Cout": 64, "K": 147, **times})
+            continue
         if isinstance(st, FusedStep):
             rows.append({"name": st.name, "flops": int(st.flops), "algorithmic_bytes": int(st.algorithmic_bytes), "tile": "bottleneck10x16",
                          "split_k": 1, "precision": 2, "slab_bytes": 0, "M": int(d.N * d.H * d.W), "Cout": int(d.Cout),
@@ -279,7 +286,7 @@ def pmc_child(args, dev):
     with torch.inference_mode():
         table = json.load(open(args.tiles_file)) if args.tiles_file and os.path.exists(args.tiles_file) else None
         if table is not None:
-            model.extractor.set_fuse_bottleneck(bool(table.get("fuse_bottleneck", False)))
+            model.extractor.set_structure(table)
         plan = model.extractor._plan_for(x)                 # packs weights, launches no conv
         if table is not None:
             plan.import_tiles(table["serial"])
@@ -307,7 +314,8 @@ def pmc_traffic(args, tiles, n_launches):
     work = tempfile.mkdtemp(prefix="tsod_pmc_", dir="/tmp")
     try:
         tiles_path = os.path.join(work, "tiles.json")
-        json.dump({"serial": tiles["serial"], "fuse_bottleneck": bool(tiles.get("fuse_bottleneck", False))}, open(tiles_path, "w"))
+        json.dump({"serial": tiles["serial"], "fuse_bottleneck": bool(tiles.get("fuse_bottleneck", False)),
+                   "fuse_stem": bool(tiles.get("fuse_stem", False))}, open(tiles_path, "w"))
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             env.pop(k, None)
@@ -325,7 +333,7 @@ def pmc_traffic(args, tiles, n_launches):
             rows = [(int(q["Dispatch_Id"]), float(q["Counter_Value"])) for q in csv.DictReader(open(files[0]))
                     if q["Counter_Name"] == counter and ("conv_igemm_kernel" in q["Kernel_Name"]
                                                          or "conv_dma_kernel" in q["Kernel_Name"]
-                                                         or "bottleneck_kernel" in q["Kernel_Name"])]
+                                                         or "bottleneck_kernel" in q["Kernel_Name"] or "stem_kernel" in q["Kernel_Name"])]
             rows.sort()
             if len(rows) < 2 * n_launches:
                 return None, f"unexpected dispatch count {len(rows)} in the {counter} pass"
@@ -535,8 +543,9 @@ def main(argv=None):
 
         def use_table(key):
             """The extractor's plan for x with table `key` pinned.  The serial / in-flight tables may belong to the launch structure
-            with one-launch bottlenecks (tiles["fuse_bottleneck"]); the f32 / bf16x3 comparison legs never do."""
-            model.extractor.set_fuse_bottleneck(bool(tiles.get("fuse_bottleneck", False)) and key in ("serial", "in_flight"))
+            with one-launch bottlenecks and stem (tiles["fuse_bottleneck"], tiles["fuse_stem"]); the f32 / bf16x3 comparison legs
+            never do."""
+            model.extractor.set_structure(tiles if key in ("serial", "in_flight") else None)
             model(x)
             pl = model.extractor._plan_for(x)
             pl.import_tiles(tiles[key])
@@ -555,6 +564,7 @@ def main(argv=None):
                 conv_sequence_time(plan, reps=20)
         precs = {"f32": (0,), "bf16x3": (1,), "auto-bf16x3": (0, 1), "auto": (0, 1, 2), "fp16x2": (0, 1, 2)}[args.precision]
         fuse_arg = {"auto": "auto", "on": True, "off": False}[args.fuse_bottleneck]
+        stem_arg = {"auto": "auto", "on": True, "off": False}[args.fuse_stem]
         # The tuning goes through the public call (FasterRCNN.tune): what a user of the module surface gets is what is timed.
         # fp16x2 needs no calibration pass: its activation scale follows every tensor per forward (range words).
         if tiles_loaded:
@@ -564,11 +574,12 @@ def main(argv=None):
             # run the same kernels in the same summation order; start-up stays far inside the driver's limit)
             if rank == 0:
                 tiles = model.tune(x, precisions=precs, in_flight=n_fly, schedules=("in_flight",) if n_fly > 1 else ("serial",),
-                                   splits=splits, in_sequence=0, in_flight_refine=0, verbose=args.verbose, fuse_bottleneck=fuse_arg)
+                                   splits=splits, in_sequence=0, in_flight_refine=0, verbose=args.verbose, fuse_bottleneck=fuse_arg, fuse_stem=stem_arg)
                 tiles["serial"] = tiles["in_flight"] = tiles.get("in_flight") or tiles["serial"]
         elif not args.no_autotune:
             tiles = model.tune(x, precisions=precs, in_flight=n_fly, splits=splits, in_sequence=args.autotune_in_sequence,
-                               in_flight_refine=args.autotune_in_flight_refine, verbose=args.verbose and rank == 0, fuse_bottleneck=fuse_arg)
+                               in_flight_refine=args.autotune_in_flight_refine, verbose=args.verbose and rank == 0, fuse_bottleneck=fuse_arg,
+                               fuse_stem=stem_arg)
             tiles.setdefault("in_flight", tiles["serial"])
         tuning_s = time.perf_counter() - t_tune
         if world > 1:
@@ -644,7 +655,8 @@ def main(argv=None):
         conv_flops = sum(st.flops for st in plan.gemm_steps)
         algo_bytes = conv_algorithmic_bytes(plan)
         precs = [step_precision(st) for st in plan.gemm_steps]
-        n_fused = len(plan.fused_steps)
+        has_stem = getattr(plan, "stem_step", None) is not None
+        n_fused = len(plan.fused_steps) - (1 if has_stem else 0)
         flops_bf = sum(st.flops * (6 if pr == 1 else 3) for st, pr in zip(plan.gemm_steps, precs) if pr >= 1) / 6.0
         peak_of = {0: F32_MFMA_PEAK_TFLOPS, 1: BF16X3_PEAK_TFLOPS, 2: FP16X2_PEAK_TFLOPS}
         ideal_ms = sum(st.flops / (peak_of[pr] * 1e12) * 1e3 for st, pr in zip(plan.gemm_steps, precs))
@@ -759,6 +771,7 @@ def main(argv=None):
                          "traffic_over_algorithmic": None if traffic is None else round(traffic * len(conv_ms) / algo_bytes, 3),
                          "kernel": f"conv_igemm_kernel / conv_dma_kernel (implicit GEMM; per layer f32 MFMA, bf16x3 or fp16x2 MFMA, register-staged or "
                                    f"fed by LDS-DMA)" + (f" + bottleneck_kernel ({n_fused} identity bottlenecks of layer1 as one launch each)" if n_fused else "")
+                                   + (" + stem_kernel (conv1 + bn1 + PReLU + max pool from the NCHW images as one launch)" if has_stem else "")
                                    + f", {len(conv_ms)} launches per forward",
                          "schedule": "serial", "flops_per_forward": conv_flops,
                          "kernel_ms_per_forward": round(conv_total_ms, 4),

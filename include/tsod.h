@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TSOD_VERSION 240 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
+#define TSOD_VERSION 241 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
                             ticket area in the workspace), pitched tsod_detections_f32, new entry points;
                             0.2.1: conv tiles fed by LDS-DMA (bf16x3), balanced K schedule (split_k = -2);
                             0.2.2: tsod_allgather_f32 + communicator helpers (RCCL bound at run time);
@@ -235,6 +235,28 @@ typedef struct tsod_bottleneck_desc {
 size_t tsod_bottleneck_wstream_bytes(int32_t Cin, int32_t Cout);
 int tsod_bottleneck_fp16x2(const tsod_bottleneck_desc *d, const float *x, const void *wstream, const float *bn, float *out,
                            tsod_stream_t stream);
+
+/* The ResNet stem in one launch (models/resnet.py:136-139: conv1 7x7 / 2 pad 3, 3 -> 64, no bias; bn1; relu = nn.PReLU (one
+ * slope); maxpool 3x3 / 2 pad 1):  out[N][PH][PW][out_pitch] (channels [0, 64)) from the images x, which are either the reference's
+ * NCHW [N][3][H][W] or the input step's NHWC with 4 floats per pixel (channel 3 is ignored).  OH = (H - 1) / 2 + 1, PH = (OH - 1) / 2 + 1
+ * (same for W).  fp16x2 arithmetic (see TSOD_PREC_FP16X2) with the pixel scale taken per tile from the tile's own input patch: no
+ * range words and no pass over the image are needed.  `wfrag` = tsod_stem_wfrag_bytes() bytes: the weights times 2^w_exp as two
+ * fp16 pieces in the MFMA fragments the lanes load, [channel block cb (2)][chunk c (14)][hi | lo][lane (64) = 32 hh + j][8 k], where
+ * lane (j, hh) holds output channel 32 cb + pi(j) (pi as in tsod_bottleneck_fp16x2) and k = 16 c + 8 hh .. + 7 with
+ * k = 32 kh + 4 kw + ci (kw = 7 and ci = 3: zeros).  `bn`: f32 [scale(64) | shift(64)].  amax_out: the pooled map's range words. */
+#define TSOD_STEM_NCHW 0
+#define TSOD_STEM_NHWC4 1
+typedef struct tsod_stem_desc {
+    int32_t N, H, W;              /* images, input height, width */
+    int32_t in_layout;            /* TSOD_STEM_NCHW / TSOD_STEM_NHWC4 */
+    int32_t out_pitch;            /* floats per pooled pixel (>= 64, multiple of 4) */
+    float slope;                  /* PReLU slope */
+    int32_t w_exp;                /* the weights in wfrag are scaled by 2^w_exp */
+    int32_t *range_flag;          /* optional, as in tsod_conv2d_desc (raised by non-finite input) */
+    uint32_t *amax_out;           /* optional range words of out */
+} tsod_stem_desc;
+size_t tsod_stem_wfrag_bytes(void);
+int tsod_stem_fp16x2(const tsod_stem_desc *d, const float *x, const void *wfrag, const float *bn, float *out, tsod_stream_t stream);
 
 /* nn.Linear (nets/classify.py:13,15): out[M,N] = in[M,K] @ w[N,K]^T + bias.  K % 4 == 0. */
 int tsod_linear_f32(const float *in, int32_t M, int32_t K, int32_t in_pitch, const float *w /* [N][K] */,

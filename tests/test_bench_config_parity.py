@@ -46,7 +46,7 @@ def _tile_tables():
                    glob.glob(os.path.join(ROOT, "profiles", "r*_b1_autotuned_tiles.json")))       # round 3 naming
     for f in files:
         d = json.load(open(f))
-        out += [(f, None)] if isinstance(d, list) else [(f, k) for k in sorted(d) if k not in ("heads", "fp16x2_exps")]   # heads: the two GEMMs outside the plan; exps: not a table
+        out += [(f, None)] if isinstance(d, list) else [(f, k) for k in sorted(d) if isinstance(d[k], list)]   # (heads, structure flags: not tables)
     return out
 
 
@@ -57,23 +57,27 @@ def test_detector_with_the_committed_autotuned_tile_tables(dev, r50, table):
     from two_stage_object_detection_amd.testing import compare_detector_outputs
     model, sd, x, ref = r50
     table, key = table
-    tiles = json.load(open(table))
-    tiles = tiles if key is None else tiles[key]
+    blob = json.load(open(table))
+    tiles = blob if key is None else blob[key]
+    # (the comparison legs' tables "f32" / "bf16x3" are always recorded on the plain structure)
+    structure = {k: bool(blob.get(k, False)) for k in ("fuse_bottleneck", "fuse_stem")} if key in ("serial", "in_flight") else {}
     xg = x.to(dev)
     legacy = any(r[0].endswith(".downsample") for r in tiles)       # tables recorded before the shortcut fusion: 53 convs
     with torch.inference_mode():
         if legacy:
             model.extractor.fuse_shortcut = False
             model.extractor.invalidate_packed()
+        model.extractor.set_structure(structure)                    # (round 4 on: a table belongs to a launch structure)
         model(xg)
         plan = model.extractor._plan_for(xg)
-        assert len(plan.conv_steps) == (53 if legacy else 49)
+        assert len(plan.conv_steps) == (53 if legacy else 49) - (6 if structure.get("fuse_bottleneck") else 0) - (1 if structure.get("fuse_stem") else 0)
         before = plan.export_tiles()
         plan.import_tiles(tiles)
         assert plan.export_tiles() == [tuple(t) + ((0,) if len(t) == 3 else ()) for t in tiles]
         got = [o.cpu() for o in model(xg)]
         model.raise_if_error()
         plan.import_tiles(before)                                # leave the shared model as the other tests expect it
+        model.extractor.set_structure(None)
         if legacy:
             model.extractor.fuse_shortcut = True
             model.extractor.invalidate_packed()
@@ -409,7 +413,7 @@ def test_detector_with_one_launch_bottlenecks(dev, r50):
             print("one-launch bottlenecks, cost-model plan:", rep)
             assert rep["ok"] and rep["rows_positional_mismatch"] <= 4 and rep["rows_unmatched"] == 0 and rep["class_mismatch"] == 0, rep
             # what bench.py does: tune() decides the structure by timing one pass with and without; force it on to gate the form
-            table = model.tune(xg, precisions=(0, 1, 2), in_flight=2, reps=2, fuse_bottleneck=True)
+            table = model.tune(xg, precisions=(0, 1, 2), in_flight=2, reps=2, fuse_bottleneck=True, fuse_stem=False)
             assert table["fuse_bottleneck"] is True and len(table["serial"]) == 43 and len(table["in_flight"]) == 43
             for depth, sched in ((1, "serial"), (2, "in_flight")):
                 server = InFlightDetector(model, xg, depth=depth, tiles=table)
@@ -419,11 +423,72 @@ def test_detector_with_one_launch_bottlenecks(dev, r50):
                 print("one-launch bottlenecks, tuned,", sched, r)
                 assert r["ok"] and r["rows_positional_mismatch"] <= 4 and r["rows_unmatched"] == 0 and r["class_mismatch"] == 0, r
             auto = model.tune(xg, precisions=(0, 1, 2), schedules=("serial",), reps=2, heads=False)
-            print("tune(fuse_bottleneck='auto') chose", auto["fuse_bottleneck"])
-            assert len(auto["serial"]) == (43 if auto["fuse_bottleneck"] else 49)
-            assert model.extractor.fuse_bottleneck == auto["fuse_bottleneck"]
+            print("tune(fuse_bottleneck='auto', fuse_stem='auto') chose", auto["fuse_bottleneck"], auto["fuse_stem"])
+            assert len(auto["serial"]) == (43 if auto["fuse_bottleneck"] else 49) - (1 if auto["fuse_stem"] else 0)
+            assert model.extractor.fuse_bottleneck == auto["fuse_bottleneck"] and model.extractor.fuse_stem == auto["fuse_stem"]
     finally:
-        model.extractor.set_fuse_bottleneck(False)
+        model.extractor.set_structure(None)
+        model.rpn.__dict__.get("_gemm_choice", {}).clear()
+        model.head.__dict__.get("_gemm_choice", {}).clear()
+        model.extractor.drop_plan(slot=1)
+
+
+def test_detector_with_the_one_launch_stem(dev, r50):
+    """conv1 + bn1 + PReLU + max pool as ONE launch (tsod_stem_fp16x2) that reads the images where the caller holds them.  The
+    detector with that stem - under the cost model's f32 plan for everything else, from NCHW images and from the input step's
+    NHWC4 images, and in the form FasterRCNN.tune serves - against the oracle: same RoIs; inputs 300x larger / 1000x smaller go
+    through (the pixel scale is per tile); a NaN pixel raises."""
+    from two_stage_object_detection_amd._ffi import NHWC4Images, TsodError
+    from two_stage_object_detection_amd.serving import InFlightDetector
+    from two_stage_object_detection_amd.testing import compare_detector_outputs
+    model, sd, x, ref = r50
+    xg = x.to(dev)
+    try:
+        with torch.inference_mode():
+            model.extractor.set_fuse_stem(True)
+            got = [o.cpu() for o in model(xg)]
+            model.raise_if_error()
+            plan = model.extractor._plan_for(xg)
+            assert plan.stem_step is not None and plan.gemm_steps[0] is plan.stem_step and len(plan.conv_steps) == 48
+            assert plan.stem_step.desc.amax_out and plan.stem_step.desc.in_layout == 0
+            rep = compare_detector_outputs(got, ref)
+            print("one-launch stem, cost-model plan, NCHW:", rep)
+            assert rep["ok"] and rep["rows_positional_mismatch"] <= 4 and rep["rows_unmatched"] == 0 and rep["class_mismatch"] == 0, rep
+            # the same images as the input step hands them over: straight from the caller's buffer, bit-equal features
+            feat = model.extractor.forward_nhwc(xg).clone()
+            x4 = torch.zeros((xg.shape[0], xg.shape[2], xg.shape[3], 4), device=dev)
+            x4[..., :3] = xg.permute(0, 2, 3, 1)
+            feat4 = model.extractor.forward_nhwc(NHWC4Images(x4))
+            assert plan.stem_step.desc.in_layout == 1 and torch.equal(feat4, feat)
+            # other ranges: no calibration, no range words for the image
+            for gain in (300.0, 1e-3):
+                f_f32 = None
+                for on in (False, True):
+                    model.extractor.set_fuse_stem(on)
+                    f = model.extractor.forward_nhwc(xg * gain).clone()
+                    model.raise_if_error()
+                    if on:
+                        err = (f - f_f32).abs().max().item() / f_f32.abs().max().item()
+                        print("gain", gain, "feature map, one-launch stem vs three launches:", err)
+                        assert err <= 2e-5, (gain, err)
+                    f_f32 = f
+            bad = xg.clone()
+            bad[0, 1, 100, 200] = float("nan")
+            model.extractor.forward_nhwc(bad)
+            with pytest.raises(TsodError, match="non-finite"):
+                model.raise_if_error()
+            # what bench.py serves: tune() decides by timing; force it on to gate the form
+            table = model.tune(xg, precisions=(0, 1, 2), in_flight=2, reps=2, fuse_stem=True)
+            assert table["fuse_stem"] is True and len(table["serial"]) == (42 if table["fuse_bottleneck"] else 48)
+            for depth, sched in ((1, "serial"), (2, "in_flight")):
+                server = InFlightDetector(model, xg, depth=depth, tiles=table)
+                outs = [o.cpu() for o in server.result(server.submit(xg))]
+                server.drain()
+                r = compare_detector_outputs(outs[:4], ref)
+                print("one-launch stem, tuned,", sched, r)
+                assert r["ok"] and r["rows_positional_mismatch"] <= 4 and r["rows_unmatched"] == 0 and r["class_mismatch"] == 0, r
+    finally:
+        model.extractor.set_structure(None)
         model.rpn.__dict__.get("_gemm_choice", {}).clear()
         model.head.__dict__.get("_gemm_choice", {}).clear()
         model.extractor.drop_plan(slot=1)
@@ -463,8 +528,8 @@ def test_config3_batch16_in_the_form_bench_times(dev):
     xg = x.to(dev)
     with torch.inference_mode():
         table = model.tune(xg, precisions=(0, 1, 2), in_flight=2, reps=2)
-        assert set(table) == {"serial", "in_flight", "heads", "fuse_bottleneck"}
-        assert len(table["serial"]) == len(table["in_flight"]) == (43 if table["fuse_bottleneck"] else 49)
+        assert set(table) == {"serial", "in_flight", "heads", "fuse_bottleneck", "fuse_stem"}
+        assert len(table["serial"]) == len(table["in_flight"]) == (43 if table["fuse_bottleneck"] else 49) - (1 if table["fuse_stem"] else 0)
         n_h2 = sum(1 for r in table["serial"] if r[3] == 2)
         for sched, depth in (("serial", 1), ("in_flight", 2)):
             server = InFlightDetector(model, xg, depth=depth, tiles=table)
@@ -474,7 +539,8 @@ def test_config3_batch16_in_the_form_bench_times(dev):
                 outs = [o.cpu() for o in server.result(t)]
             server.drain()
             worst = _check_images(outs[:4], sd, x, "resnet50", (0, 7, 15), max_pos=6)
-            print("config 3 as benched:", sched, "fp16x2 layers", n_h2, "one-launch bottlenecks:", table["fuse_bottleneck"], worst)
+            print("config 3 as benched:", sched, "fp16x2 layers", n_h2, "one-launch bottlenecks:", table["fuse_bottleneck"],
+                  "one-launch stem:", table["fuse_stem"], worst)
     assert n_h2 >= 20, table["serial"]
 
 

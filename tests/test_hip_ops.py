@@ -969,3 +969,51 @@ def test_bottleneck_fused_matches_the_f64_block(ops, dev, N, H, W, C, gain):
         from two_stage_object_detection_amd._ffi import TsodError
         with pytest.raises(TsodError):                                 # channel counts must be multiples of 64
             ops.bottleneck_fused(xn, stream, exps, bnv, 96, slope)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,gain", [(1, 37, 53, 1.0), (2, 64, 130, 1.0), (1, 131, 260, 300.0), (1, 200, 336, 1e-3), (1, 9, 11, 1.0)])
+def test_stem_fused_matches_the_f64_stem(ops, dev, N, H, W, gain):
+    """tsod_stem_fp16x2: conv 7x7/2 + BN + PReLU + max pool 3x3/2 in one launch against the f64 CPU stem, from NCHW images and from
+    NHWC4 images: tile edges (sizes that are not multiples of the 4 x 16 pooled tile, one-tile and multi-tile images, odd conv
+    sizes: the pool's -inf padding), the conv's zero padding, the tile-local pixel scale (inputs 300x larger / 1000x smaller than
+    unit range), the abs-max left for the consumer, and non-finite input raising the flag."""
+    from two_stage_object_detection_amd._ffi import NHWC4Images
+    g = torch.Generator().manual_seed(77 + H)
+    x = torch.randn(N, 3, H, W, generator=g) * gain
+    w = torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147)
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2 * gain
+    slope = 0.25
+    y = torch.nn.functional.conv2d(x.double(), w.double(), stride=2, padding=3) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    y = torch.clamp(y, min=0) + slope * torch.clamp(y, max=0)
+    ref = torch.nn.functional.max_pool2d(y, 3, 2, 1).float()
+    wfrag, e = ops.pack_stem_wfrag(w.to(dev))
+    bn = torch.cat([scale, shift]).to(dev)
+    words = ops.new_amax_words(dev, 2)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    xd = x.to(dev)
+    out = ops.stem_fused(xd, wfrag, e, bn, slope, amax_out=words[0], range_flag=flag)
+    assert tuple(out.shape) == (N, ref.shape[2], ref.shape[3], 64)
+    got = ops.nhwc_to_nchw(out).cpu()
+    tol = (3e-6 * math.sqrt(147) + 1e-5) * float(y.abs().max()) + 1e-6 * gain
+    err = (got - ref).abs().max().item()
+    assert err <= tol, (err, tol)
+    assert int(flag.item()) == 0
+    assert ops.amax_value(words[0]) == float(out.abs().max())
+    # the same images as the input step writes them (NHWC, 4 floats per pixel; whatever sits in channel 3 is ignored): bit-equal
+    x4 = torch.full((N, H, W, 4), 7.0, device=dev)
+    x4[..., :3] = xd.permute(0, 2, 3, 1)
+    out4 = ops.stem_fused(NHWC4Images(x4), wfrag, e, bn, slope, amax_out=words[1], range_flag=flag)
+    assert torch.equal(out4, out) and int(flag.item()) == 0
+    # three launches of the existing kernels (layout, fp16x2 implicit GEMM with range words, max pool): same arithmetic, other summation order
+    if gain == 1.0 and H > 16:
+        xn = ops.nchw_to_nhwc(xd, 4)
+        wp = ops.pack_conv_weight(w.to(dev), cin_pad=4, kw_pad=8)
+        y3 = ops.conv2d_nhwc(xn, wp, stride=2, pad=3, kw_logical=7, scale=scale.to(dev), shift=shift.to(dev), act=1, slope=slope, precision=2,
+                             amax_in=ops.absmax(xn, ops.new_amax_words(dev, 1)))
+        p3 = ops.maxpool3x3s2_nhwc(y3)
+        assert (p3 - out).abs().max().item() <= tol
+    xbad = xd.clone()
+    xbad[0, 1, H // 2, W // 3] = float("nan")
+    ops.stem_fused(xbad, wfrag, e, bn, slope, range_flag=flag)
+    assert int(flag.item()) == 1

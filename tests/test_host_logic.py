@@ -258,14 +258,14 @@ def test_head_choices_roundtrip_as_json():
 
 
 def test_fp16x2_host_side_choices():
-    """The host side of the fp16x2 arithmetic: which tiles have it (every bf16x3 tile but the two 64-row LDS-DMA shapes), the
+    """The host side of the fp16x2 arithmetic: which tiles have it (every bf16x3 tile but the two 64-row LDS-DMA shapes, plus d192x128), the
     activation exponent picked for a measured range (16x headroom under fp16's 65504, clamped), and the weight exponent
     (max |w| just below 2^14)."""
     import torch
     from two_stage_object_detection_amd import _ffi
     from two_stage_object_detection_amd.engine import FP16X2_A_SCALE_EXP, fp16x2_activation_exp
     from two_stage_object_detection_amd.hip_ops import fp16x2_weight_scale_exp
-    assert set(_ffi.FP16X2_TILE_IDS) == set(_ffi.BF16X3_TILE_IDS) - {18, 20} and 22 in _ffi.FP16X2_TILE_IDS
+    assert set(_ffi.FP16X2_TILE_IDS) == (set(_ffi.BF16X3_TILE_IDS) - {18, 20}) | {23} and 22 in _ffi.FP16X2_TILE_IDS   # (d192x128: fp16x2 only)
     assert _ffi.PREC_NAMES[_ffi.PREC_FP16X2] == "fp16x2" and FP16X2_A_SCALE_EXP == 4
     for m in (1e-3, 0.7, 100.0, 4093.0, 3e4, 1e9):
         e = fp16x2_activation_exp(m)
@@ -370,3 +370,36 @@ def test_bottleneck_weight_stream_layout():
         assert [pi(4 * h + (e & 3) + 8 * (e >> 2)) for e in range(16)] == list(range(16 * h, 16 * h + 16))
     for m in (max(abs(float(w.abs().max()) * 2.0 ** e) for w, e in ((w1, e1), (w2, e2), (w3, e3))),):
         assert 8192.0 <= m < 16384.0                                # every weight matrix scaled to just below 2^14
+
+
+def test_stem_weight_fragment_layout():
+    """hip_ops.pack_stem_wfrag against the layout include/tsod.h documents (what stem_kernel's lanes load): [channel block cb][chunk c]
+    [hi | lo][lane = 32 hh + j][8 k], lane (j, hh) of block cb holding output channel 32 cb + pi(j) and k = 16 c + 8 hh .. + 7 with
+    k = 32 kh + 4 kw + ci; kw = 7 and ci = 3 are zeros; hi + lo reproduce 2^e * w to fp16x2 accuracy."""
+    from two_stage_object_detection_amd import hip_ops
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    frag, e = hip_ops.pack_stem_wfrag(w)
+    assert frag.dtype == torch.uint8 and frag.numel() == 2 * 14 * 2 * 1024
+    f = frag.view(torch.float16).view(2, 14, 2, 64, 8).float()
+
+    def pi(j):
+        return 16 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3)
+    wk = torch.zeros(64, 7, 8, 4)
+    wk[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    wk = wk.reshape(64, 224) * (2.0 ** e)
+    assert float(wk.abs().max()) < 16384.0
+    for cb in (0, 1):
+        for lane in (0, 3, 12, 31, 32, 45, 63):
+            j, hh = lane & 31, lane >> 5
+            for c in range(14):
+                want = wk[32 * cb + pi(j), 16 * c + 8 * hh:16 * c + 8 * hh + 8]
+                hi, lo = f[cb, c, 0, lane], f[cb, c, 1, lane]
+                assert torch.equal(hi, want.half().float())
+                assert torch.equal(lo, (want - want.half().float()).half().float())
+                # k = 16 c + 8 hh + i: filter row c >> 1, filter columns 4 (c & 1) + 2 hh and + 1, channels 0..3 of each
+                kh, kw0 = c >> 1, 4 * (c & 1) + 2 * hh
+                for i in range(8):
+                    kw, ci = kw0 + (i >> 2), i & 3
+                    ref = 0.0 if kw == 7 or ci == 3 else float(w[32 * cb + pi(j), ci, kh, kw]) * 2.0 ** e
+                    assert abs(float(hi[i] + lo[i]) - ref) <= abs(ref) * 2.0 ** -21

@@ -48,9 +48,10 @@ def _kernel_notes(tmp_path):
 
 def test_conv_kernels_use_no_scratch_memory(tmp_path):
     kernels = _kernel_notes(tmp_path)
-    conv = {k: v for k, v in kernels.items() if "conv_dma_kernel" in k or "conv_igemm_kernel" in k or "bottleneck_kernel" in k}
-    assert len(conv) >= 31, sorted(kernels)[:5]                    # 12 LDS-DMA + 23 register-staged instantiations + the fused bottleneck
+    conv = {k: v for k, v in kernels.items() if "conv_dma_kernel" in k or "conv_igemm_kernel" in k or "bottleneck_kernel" in k or "stem_kernel" in k}
+    assert len(conv) >= 32, sorted(kernels)[:5]                    # 12 LDS-DMA + 23 register-staged instantiations + the fused bottleneck + stem
     assert any("bottleneck_kernel" in k and v.get("vgpr_count", 999) <= 256 for k, v in conv.items())   # two workgroups per CU
+    assert any("stem_kernel" in k and v.get("vgpr_count", 999) <= 256 for k, v in conv.items())         # (its LDS: a static_assert)
     bad = {k: v for k, v in conv.items() if v.get("private_segment_fixed_size", 0) != 0 or v.get("vgpr_spill_count", 0) != 0}
     assert not bad, bad
     # two waves per SIMD for the LDS-DMA tiles (512-thread workgroups at one per CU, 256-thread ones at two): 256 registers each

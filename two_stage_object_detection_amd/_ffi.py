@@ -59,6 +59,16 @@ class BottleneckDesc(Structure):
     ]
 
 
+class StemDesc(Structure):
+    """Mirror of ``tsod_stem_desc`` (include/tsod.h)."""
+    _fields_ = [
+        ("N", c_int32), ("H", c_int32), ("W", c_int32), ("in_layout", c_int32), ("out_pitch", c_int32), ("slope", c_float),
+        ("w_exp", c_int32), ("range_flag", c_void_p), ("amax_out", c_void_p),
+    ]
+
+
+STEM_NCHW, STEM_NHWC4 = 0, 1
+
 # name -> (restype, argtypes); every symbol include/tsod.h declares
 _SIGNATURES = {
     "tsod_status_str": (c_char_p, [c_int]),
@@ -77,6 +87,8 @@ _SIGNATURES = {
                                      c_void_p, c_size_t, c_void_p]),
     "tsod_bottleneck_wstream_bytes": (c_size_t, [c_int32, c_int32]),
     "tsod_bottleneck_fp16x2": (c_int, [POINTER(BottleneckDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tsod_stem_wfrag_bytes": (c_size_t, []),
+    "tsod_stem_fp16x2": (c_int, [POINTER(StemDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tsod_linear_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32,
                                 c_void_p, c_size_t, c_void_p]),
     "tsod_linear_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
@@ -159,8 +171,8 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.tsod_version() != 240:
-            raise TsodError(f"{LIB_PATH} is version {l.tsod_version()}, this package binds version 240 of include/tsod.h: rebuild it "
+        if l.tsod_version() != 241:
+            raise TsodError(f"{LIB_PATH} is version {l.tsod_version()}, this package binds version 241 of include/tsod.h: rebuild it "
                             "(`make -C two_stage_object_detection_amd/csrc`)")
         _lib = l
     return _lib

@@ -103,6 +103,19 @@ class FusedBottleneckWeights:
             torch.cuda.current_stream(self.stream.device).synchronize()
 
 
+class FusedStemWeights:
+    """ResNet's conv1 + bn1 + PReLU (models/resnet.py:136-138) packed for tsod_stem_fp16x2: the 7x7 weights as per-lane MFMA
+    fragments of two fp16 pieces, the folded BatchNorm as one vector, the PReLU slope."""
+
+    def __init__(self, conv, bn, relu, device):
+        from . import hip_ops
+        self.wfrag, self.w_exp = hip_ops.pack_stem_wfrag(conv.weight.detach().float().to(device))
+        self.bn = torch.cat(fold_bn(bn)).to(device)
+        self.slope = prelu_slope(relu)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(self.wfrag.device).synchronize()
+
+
 class FusedStep:
     """One tsod_bottleneck_fp16x2 launch of a plan, with what the timing / roofline code asks of a ConvStep."""
     precision = _ffi.PREC_FP16X2
@@ -237,6 +250,8 @@ class Plan:
         self.conv_steps: list[ConvStep] = []
         self.fused_steps: list[FusedStep] = []                   # whole-bottleneck launches (tsod_bottleneck_fp16x2)
         self.gemm_steps: list = []           # every matrix launch in forward order: ConvStep | FusedStep (timing, roofline)
+        self.stem_step = None                # the one-launch stem (tsod_stem_fp16x2), whose input pointer stage_input binds per forward
+        self._bound_input = None
         self.keep: list = []                 # keeps descriptors / tensors alive
         self._ws_slots: list[tuple[list, int, int, int]] = []   # (args, ptr index, size index, bytes)
         self.workspace: torch.Tensor | None = None
@@ -392,6 +407,38 @@ class Plan:
         self.flops += flops
         self.keep.extend([d, x, out, fb])
         return out
+
+    def stem(self, fs: "FusedStemWeights", N: int, H: int, W: int, out: torch.Tensor, name: str = "stem"):
+        """images [N,3,H,W] (NCHW) or NHWC4Images -> out [N,PH,PW,64]: conv1 + bn1 + PReLU + max pool as ONE launch
+        (tsod_stem_fp16x2; the pixel scale is each tile's own).  The images are whatever ``stage_input`` bound last: the launch
+        reads them where the caller holds them - no layout pass, no copy."""
+        d = _ffi.StemDesc()
+        d.N, d.H, d.W, d.in_layout, d.out_pitch = N, H, W, _ffi.STEM_NHWC4, out.shape[3]
+        d.slope, d.w_exp = float(fs.slope), int(fs.w_exp)
+        d.range_flag = ptr(self.range_flag)
+        d.amax_out = self.amax_ptr(out) or None
+        args = [byref(d), ptr(self.input_nhwc), ptr(fs.wfrag), ptr(fs.bn), ptr(out)]
+        self.steps.append([lib().tsod_stem_fp16x2, args])
+        oh, ow = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        flops = 2 * N * oh * ow * 64 * 147
+        alg = 4 * (N * H * W * 3 + out.shape[0] * out.shape[1] * out.shape[2] * 64 + 64 * 147)
+        st = FusedStep(name, self.steps[-1][0], args, d, flops, alg)
+        self.stem_step = st
+        self.fused_steps.append(st)
+        self.gemm_steps.append(st)
+        self.flops += flops
+        self.keep.extend([d, out, fs])
+        return out
+
+    def bind_input(self, x) -> None:
+        """Point the one-launch stem at the images of the next forward (an NCHW tensor or NHWC4Images; kept alive until the next
+        call).  A HIP graph captured from the plan replays the pointer it was captured with."""
+        st = self.stem_step
+        nhwc4 = isinstance(x, _ffi.NHWC4Images)
+        t = x.data if nhwc4 else x.contiguous()
+        st.desc.in_layout = _ffi.STEM_NHWC4 if nhwc4 else _ffi.STEM_NCHW
+        st.args[1] = ptr(t)
+        self._bound_input = t
 
     def finalize(self):
         """Size the shared K-slice workspace (stream order makes sharing safe) and bind it.  Its head holds the arrival
@@ -834,6 +881,7 @@ class PlanOwner:
     conv_precision = "f32"       # "f32" | "bf16x3" | "fp16x2": default arithmetic of the dense convs of plans built from now on
     fuse_bottleneck = False      # ResNet: identity bottlenecks with 64 mid channels (layer1.1, layer1.2) as ONE launch each
                                  # (tsod_bottleneck_fp16x2; FasterRCNN.tune switches it on where it measures faster)
+    fuse_stem = False            # ResNet: conv1 + bn1 + PReLU + max pool (and the NCHW -> NHWC pass) as ONE launch (tsod_stem_fp16x2)
     fuse_shortcut = True         # ResNet: a bottleneck's last 1x1 conv + its projection shortcut as one stacked-K GEMM
                                  # (set False + invalidate_packed() for the one-launch-per-conv plan, e.g. to pin a tile
                                  # table recorded from it)
@@ -843,6 +891,20 @@ class PlanOwner:
         if bool(on) != bool(self.fuse_bottleneck):
             self.fuse_bottleneck = bool(on)
             self.__dict__["_plans"] = OrderedDict()
+        return self
+
+    def set_fuse_stem(self, on: bool):
+        """Switch the one-launch stem on / off for plans built from now on (existing plans are dropped, packed weights stay)."""
+        if bool(on) != bool(self.fuse_stem):
+            self.fuse_stem = bool(on)
+            self.__dict__["_plans"] = OrderedDict()
+        return self
+
+    def set_structure(self, table) -> "PlanOwner":
+        """The launch structure a tuning table was made for (``FasterRCNN.tune``: "fuse_bottleneck", "fuse_stem"; absent = off)."""
+        table = table or {}
+        self.set_fuse_bottleneck(bool(table.get("fuse_bottleneck", False)))
+        self.set_fuse_stem(bool(table.get("fuse_stem", False)))
         return self
 
     def set_conv_precision(self, precision: str):
@@ -972,6 +1034,9 @@ def stage_input(plan: "Plan", x) -> None:
     into ``plan.input_nhwc``, see ``input_buffer`` of the backbones)."""
     from ._ffi import NHWC4Images
     plan.reset_amax()                                   # the range words of this forward start from zero
+    if plan.stem_step is not None:                      # the one-launch stem reads the images where they are
+        plan.bind_input(x)
+        return
     a_in = plan.amax_ptr(plan.input_nhwc)
     if isinstance(x, NHWC4Images):
         if x.data.data_ptr() != plan.input_nhwc.data_ptr():

@@ -284,6 +284,49 @@ def bottleneck_fused(x: torch.Tensor, wstream: torch.Tensor, w_exps, bn: torch.T
     return out
 
 
+def pack_stem_wfrag(w: torch.Tensor):
+    """The weight fragments of tsod_stem_fp16x2 (include/tsod.h): conv1's weight [64, 3, 7, 7] f32 -> (uint8 tensor of
+    tsod_stem_wfrag_bytes, w_exp).  K = (kh, kw padded to 8, ci padded to 4) = 224; [channel block cb (2)][chunk c (14)][hi | lo]
+    [lane (64) = 32 hh + j][8 k] fp16, lane (j, hh) holding output channel 32 cb + pi(j) and k = 16 c + 8 hh .. + 7.  Index
+    arithmetic only; the fp16 roundings are torch's round-to-nearest-even (the bits of the device's conversions)."""
+    assert tuple(w.shape) == (64, 3, 7, 7), tuple(w.shape)
+    dev = w.device
+    e = fp16x2_weight_scale_exp(w)
+    wk = torch.zeros((64, 7, 8, 4), dtype=torch.float32, device=dev)
+    wk[:, :, :7, :3] = w.detach().float().permute(0, 2, 3, 1)
+    sc = wk.reshape(64, 224) * (2.0 ** e)
+    hi = sc.half()
+    lo = (sc - hi.float()).half()
+    i = torch.arange(32)
+    pi = (16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3)).to(dev)
+    pl = torch.stack([hi, lo], dim=0).view(2, 2, 32, 14, 2, 8)[:, :, pi]     # [plane, cb, j, c, hh, 8]: row j <- channel 32 cb + pi(j)
+    out = pl.permute(1, 3, 0, 4, 2, 5).contiguous().view(-1).view(torch.uint8)   # [cb, c, plane, hh, j, 8]
+    assert out.numel() == lib().tsod_stem_wfrag_bytes()
+    return out, e
+
+
+def stem_fused(x, wfrag: torch.Tensor, w_exp: int, bn: torch.Tensor, slope: float, *, out=None, amax_out=None, range_flag=None):
+    """tsod_stem_fp16x2: conv1 7x7/2 + BN + PReLU + max pool 3x3/2 of ResNet in one launch.  ``x``: an NCHW tensor [N,3,H,W] or
+    ``NHWC4Images``; returns the pooled NHWC map [N,PH,PW,64]."""
+    nhwc4 = isinstance(x, _ffi.NHWC4Images)
+    t = x.data if nhwc4 else x.contiguous()
+    require_cuda(t, "stem_fused")
+    if nhwc4:
+        N, H, W, _ = t.shape
+    else:
+        N, _, H, W = t.shape
+    oh, ow = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((N, ph, pw, 64), dtype=torch.float32, device=t.device)
+    d = _ffi.StemDesc()
+    d.N, d.H, d.W, d.in_layout, d.out_pitch = N, H, W, (_ffi.STEM_NHWC4 if nhwc4 else _ffi.STEM_NCHW), out.shape[3]
+    d.slope, d.w_exp = float(slope), int(w_exp)
+    d.range_flag, d.amax_out = ptr(range_flag) or None, _word_ptr(amax_out)
+    check(lib().tsod_stem_fp16x2(byref(d), ptr(t), ptr(wfrag), ptr(bn), ptr(out), stream_ptr()), "stem_fused")
+    return out
+
+
 def _word_ptr(w):
     """None / a raw device pointer / a tensor of range words -> what the descriptor takes."""
     if w is None:

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import hip_ops
 from .._ffi import ACT_NONE, ACT_PRELU, TsodError, lib, ptr, require_cuda
-from ..engine import FusedBottleneckWeights, FusedShortcutConv, PackedConv, Plan, PlanOwner, prelu_slope
+from ..engine import FusedBottleneckWeights, FusedShortcutConv, FusedStemWeights, PackedConv, Plan, PlanOwner, prelu_slope
 
 
 def _conv(cin, cout, k, stride=1, pad=0, groups=1):
@@ -180,15 +180,22 @@ class ResNet(PlanOwner, nn.Module):
         plan.fuse_bottleneck = bool(self.fuse_bottleneck)
         x4 = plan.pool.alloc((N, H, W, 4))
         plan.input_nhwc = x4
-        stem = plan.packed("conv1", lambda: PackedConv(self.conv1.weight, device, bn=self.bn1, stride=2, pad=3, act=ACT_PRELU,
-                                                       slope=prelu_slope(self.relu), cin_pad=4, kw_pad=8))
-        oh, ow = stem.out_hw(H, W)
-        s_out = plan.conv(stem, x4, plan.pool.alloc((N, oh, ow, 64)), name="conv1")
+        oh, ow = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
-        cur = plan.pool.alloc((N, ph, pw, 64))
-        plan.call(lib().tsod_maxpool3x3s2_f32, ptr(s_out), N, oh, ow, 64, 64, ptr(cur), 64, keep=(s_out, cur))
-        plan.alias_amax(cur, s_out)          # range words: max |pooled| <= max |stem output|
-        plan.pool.release(s_out)
+        if self.fuse_stem and tuple(self.conv1.weight.shape) == (64, 3, 7, 7):
+            # conv1 + bn1 + PReLU + max pool as ONE launch that reads the images where stage_input finds them (NCHW or NHWC4):
+            # no layout pass, the 64-channel conv output never leaves the CU (tsod_stem_fp16x2)
+            fs = plan.packed("conv1.fused", lambda: FusedStemWeights(self.conv1, self.bn1, self.relu, device))
+            cur = plan.stem(fs, N, H, W, plan.pool.alloc((N, ph, pw, 64)), name="conv1+maxpool")
+        else:
+            stem = plan.packed("conv1", lambda: PackedConv(self.conv1.weight, device, bn=self.bn1, stride=2, pad=3, act=ACT_PRELU,
+                                                           slope=prelu_slope(self.relu), cin_pad=4, kw_pad=8))
+            assert (oh, ow) == tuple(stem.out_hw(H, W))
+            s_out = plan.conv(stem, x4, plan.pool.alloc((N, oh, ow, 64)), name="conv1")
+            cur = plan.pool.alloc((N, ph, pw, 64))
+            plan.call(lib().tsod_maxpool3x3s2_f32, ptr(s_out), N, oh, ow, 64, 64, ptr(cur), 64, keep=(s_out, cur))
+            plan.alias_amax(cur, s_out)          # range words: max |pooled| <= max |stem output|
+            plan.pool.release(s_out)
         for li in range(1, 5):
             for bi, blk in enumerate(getattr(self, f"layer{li}")):
                 nxt = blk._emit(plan, cur, f"layer{li}.{bi}")

@@ -120,7 +120,7 @@ class FasterRCNN(nn.Module):
             return rpn_choice, self.head.autotune(fc7, feat_amax, flag)
 
     def tune(self, example, precisions=(0, 1, 2), in_flight=1, schedules=("serial", "in_flight"), splits=None, in_sequence=None,
-             in_flight_refine=None, reps=3, heads=True, fuse_bottleneck="auto", verbose=False):
+             in_flight_refine=None, reps=3, heads=True, fuse_bottleneck="auto", fuse_stem="auto", verbose=False):
         """Autotune every GEMM of the forward for ``example``'s geometry ([B,3,H,W] on the GPU) and pin the result: per conv
         layer the fastest (tile, K-slice schedule, arithmetic) among ``precisions`` (0 f32 MFMA, 1 bf16x3, 2 fp16x2 - all three
         f32-accurate; the fp16x2 scale follows every tensor per forward through its range words, so no calibration pass and no
@@ -132,8 +132,11 @@ class FasterRCNN(nn.Module):
         (``in_flight_refine``, default 3 below batch 4) re-tried with every slot's stream running the whole conv sequence.
         ``fuse_bottleneck`` ("auto" | True | False; needs fp16x2 among ``precisions``): ResNet's identity bottlenecks with 64 mid
         channels as ONE launch each (tsod_bottleneck_fp16x2) - "auto" times one pass over the matrix launches with and without
-        and keeps the faster structure.
-        Returns the tables as plain JSON-able data {"serial": [...], "in_flight": [...], "heads": {...}, "fuse_bottleneck": bool}
+        and keeps the faster structure.  ``fuse_stem`` (same values, same condition): ResNet's conv1 + bn1 + PReLU + max pool as
+        ONE launch that reads the images where they are, NCHW or NHWC4 (tsod_stem_fp16x2: no layout pass, no 64-channel conv output
+        in memory) - "auto" times the input step + the backbone's launches with and without.
+        Returns the tables as plain JSON-able data {"serial": [...], "in_flight": [...], "heads": {...}, "fuse_bottleneck": bool,
+        "fuse_stem": bool}
         - feed it back through ``import_tuning`` (another process, another rank) or ``InFlightDetector(tiles=...)``.  Afterwards
         the plan of slot 0 runs the serial table when that was tuned, else the in-flight one."""
         from ..engine import refine_in_flight
@@ -167,6 +170,15 @@ class FasterRCNN(nn.Module):
 
         with torch.inference_mode():
             can_fuse = hasattr(ext, "set_fuse_bottleneck")
+            can_stem = hasattr(ext, "conv1") and hasattr(ext, "set_fuse_stem") and 2 in tuple(precisions) and bool(fuse_stem)
+            stem = False
+            if hasattr(ext, "set_fuse_stem"):
+                # the stem's structure first (it is no tiled GEMM: nothing of the tables depends on it, but every later timing runs
+                # on the structure that will be served)
+                ext.set_fuse_stem(False)
+                if can_stem:
+                    stem = fuse_stem is True or self._stem_pays(example, verbose)
+                    ext.set_fuse_stem(stem)
             if can_fuse:
                 ext.set_fuse_bottleneck(False)                      # every layer first gets its own best kernel
             self(example)                                           # builds the plan; leaves real activations (and range words) behind
@@ -197,17 +209,44 @@ class FasterRCNN(nn.Module):
                 table[sched] = tune_schedule(plan, sched)
             plan.import_tiles(table.get("serial") or table["in_flight"])
             table["fuse_bottleneck"] = bool(fused)
+            table["fuse_stem"] = bool(stem)
             if heads:
                 self.autotune_heads(example)
                 table["heads"] = self.head_choices()
         return table
 
+    def _stem_pays(self, example, verbose=False, reps=10) -> bool:
+        """HIP-event time of the backbone's forward (input step + every launch of its plan, cost-model tiles) with the one-launch
+        stem against the three-launch one: the structures differ only in the stem, so the difference is the stem's."""
+        from ..engine import stage_input
+        ext, times = self.extractor, {}
+        for on in (False, True):
+            ext.set_fuse_stem(on)
+            ext.forward_nhwc(example)
+            plan = ext._plan_for(example)
+            if on and plan.stem_step is None:                       # (a backbone whose stem the kernel does not cover)
+                return False
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            stage_input(plan, example)
+            plan.launch()
+            e0.record()
+            for _ in range(reps):
+                stage_input(plan, example)
+                plan.launch()
+            e1.record()
+            e1.synchronize()
+            times[on] = e0.elapsed_time(e1) / reps
+        if verbose:
+            print(f"  one-launch stem: {times[True] * 1e3:.1f} us per backbone pass against {times[False] * 1e3:.1f} us -> "
+                  f"{'one launch' if times[True] < times[False] else 'three launches'}")
+        return times[True] < times[False]
+
     def import_tuning(self, table, example, schedule="serial", slot=0):
         """Pin a table made by ``tune`` (same model, same input geometry; e.g. rank 0's on every rank) in the plan of ``slot``."""
         require_cuda(example, "FasterRCNN.import_tuning")
         self.set_head_choices(table.get("heads"))
-        if hasattr(self.extractor, "set_fuse_bottleneck"):
-            self.extractor.set_fuse_bottleneck(bool(table.get("fuse_bottleneck", False)))
+        if hasattr(self.extractor, "set_structure"):
+            self.extractor.set_structure(table)
         with torch.inference_mode():
             self(example, slot=slot)
             self.extractor._plan_for(example, slot).import_tiles(table.get(schedule) or table["serial"])

@@ -41,8 +41,8 @@ class InFlightDetector:
                 tiles = model.tune(example, in_flight=depth, schedules=("in_flight",) if depth > 1 else ("serial",))
             if isinstance(tiles, dict):
                 model.set_head_choices(tiles.get("heads"))
-                if hasattr(model.extractor, "set_fuse_bottleneck"):
-                    model.extractor.set_fuse_bottleneck(bool(tiles.get("fuse_bottleneck", False)))   # the table's launch structure
+                if hasattr(model.extractor, "set_structure"):
+                    model.extractor.set_structure(tiles)                                             # the table's launch structure
                 tiles = tiles.get("in_flight" if depth > 1 else "serial") or tiles.get("serial")
             model(example)                                               # builds slot 0's plan
             plan0 = model.extractor._plan_for(example, 0)
