@@ -14,9 +14,17 @@ def short(n):
     return m.group(1) if m else n[:60]
 
 
+_HAS_STEM = [None]
+
+
+def opens_forward(k):
+    """the first kernel of every forward: the one-launch stem, or the layout kernel where the stem is three launches"""
+    return ('stem_kernel' in k) if _HAS_STEM[0] else ('nchw_to_nhwc' in k)
+
+
 def is_gemm(k):
-    """the matrix launches of a forward: both conv kernel families and the one-launch bottleneck"""
-    return 'conv_igemm' in k or 'conv_dma' in k or 'bottleneck_kernel' in k
+    """the matrix launches of a forward: both conv kernel families, the one-launch bottleneck and the one-launch stem"""
+    return 'conv_igemm' in k or 'conv_dma' in k or 'bottleneck_kernel' in k or 'stem_kernel' in k
 
 
 def arith(k):
@@ -25,6 +33,8 @@ def arith(k):
     conv_dma_kernel<BM, BK, WAVES_K, S, BALANCED, WAVES_N, NPL> (7 arguments): NPL 3 = bf16x3, 2 = fp16x2."""
     m = re.search(r'<([^>]*)>', k)
     args = m.group(1).replace(' ', '').split(',') if m else []
+    if 'stem_kernel' in k:
+        return 'fp16x2 (one-launch stem)'
     if 'bottleneck_kernel' in k:
         return 'fp16x2 (one-launch bottleneck)'
     if 'conv_dma' in k:
@@ -56,6 +66,7 @@ ap.add_argument("--backbone", default="resnet50")
 A = ap.parse_args()
 label = A.label
 sq, dsq = load(A.sq); fe, dfe = load(A.fetch); wr, dwr = load(A.write)
+_HAS_STEM[0] = any('stem_kernel' in k for k in sq)
 print(f"# {label} - PMC counters, `bench.py --no-graph --in-flight 1` ({A.workload}), rocprofv3 --pmc, separate passes\n")
 print("Per dispatch, averaged over the dispatches of the second half of the forwards (the timed steps; the first half contains plan")
 print("building and warm-up; kernels that only ran before that - tuning candidates - are not listed).  `FETCH_SIZE` / `WRITE_SIZE` are KiB; on gfx950 `FETCH_SIZE` under-reports wide")
@@ -73,7 +84,7 @@ print("|---|---|---:|---:|---:|---:|---:|")
 tot = collections.defaultdict(lambda: [0.0, 0.0])
 def forward_starts(per):
     """dispatch ids of the layout kernel that opens every forward (eager bench: one per step)"""
-    return sorted(int(i) for k in per if 'nchw_to_nhwc' in k for i in per[k])
+    return sorted(int(i) for k in per if opens_forward(k) for i in per[k])
 
 
 def timed_only(per, items):
@@ -131,7 +142,7 @@ print("shorter than ~0.3 ms; the table uses min(measured, 2.4 GHz)).")
 
 
 def last_forward(per):
-    start = max(int(i) for k in per if 'nchw_to_nhwc' in k for i in per[k])
+    start = max(int(i) for k in per if opens_forward(k) for i in per[k])
     out = collections.defaultdict(lambda: [0, 0.0])
     for k in per:
         fam = 'conv_igemm_kernel + conv_dma_kernel' if is_gemm(k) else k

@@ -11,7 +11,9 @@ def short(n):
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 n = int(sys.argv[2])
-marks = [i for i, r in enumerate(rows) if 'nchw_to_nhwc_small' in r['Kernel_Name']]
+# the first kernel of every forward: the one-launch stem, or the layout kernel where the stem is three launches
+opener = 'stem_kernel' if any('stem_kernel' in r['Kernel_Name'] for r in rows[-200:]) else 'nchw_to_nhwc_small'
+marks = [i for i, r in enumerate(rows) if opener in r['Kernel_Name']]
 sel = rows[marks[-n]:]
 per = collections.OrderedDict()
 for r in sel:

@@ -64,6 +64,8 @@ struct Params {
     int w_exp;
     unsigned *amax_out;
     int *range_flag;
+    int dbg;                   // timing experiments only (TSOD_STEM_DBG): 1 no GEMM, 2 no BN / PReLU / conv-tile writes, 4 no pool, 8 no patch
+                               // requests and staging after the first - wrong results by design, never set by the library's callers
 };
 
 __device__ __forceinline__ float prelu(float v, float a) { return fmaxf(v, 0.f) + a * fminf(v, 0.f); }
@@ -194,7 +196,7 @@ __global__ void __launch_bounds__(256, 2) stem_kernel(const Params p) {
                 *reinterpret_cast<u32x2 *>(lds + PLANE + q * 8) = u32x2{l0, l1};
             }
         }
-        if (t + nwg < n_tiles) request_patch(tile_at(t + nwg));   // lands while this tile is computed
+        if (t + nwg < n_tiles && !(p.dbg & 8)) request_patch(tile_at(t + nwg));   // lands while this tile is computed
         __syncthreads();
 
         // ---- GEMM: acc[b] = conv pixels of block ph + 2 b (columns) x channels 32 cb + pi(rows), K = 224
@@ -214,6 +216,7 @@ __global__ void __launch_bounds__(256, 2) stem_kernel(const Params p) {
         };
         AFrag af[2];
         af[0] = aload(0, 0);
+        if (!(p.dbg & 1))
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
             // (past the last chunk: the first fragments again, for this workgroup's next tile)
@@ -239,7 +242,7 @@ __global__ void __launch_bounds__(256, 2) stem_kernel(const Params p) {
         __syncthreads();                                 // every wave is done with the patch: the conv tile goes over it
 
         // ---- BN + PReLU, -inf outside the conv output, into the conv tile: lane = pixel m, channels ch16 + 0..15
-        {
+        if (!(p.dbg & 2)) {
             const float sc = __uint_as_float((unsigned)(127 - e_a - p.w_exp) << 23);
             float sv[16], bv[16];
 #pragma unroll
@@ -270,7 +273,7 @@ __global__ void __launch_bounds__(256, 2) stem_kernel(const Params p) {
         __syncthreads();
 
         // ---- 3x3 / 2 maxima: thread = (pooled column g, channel slot s), the tile's TPH rows in turn
-        {
+        if (!(p.dbg & 4)) {
             const int s = tid_l & 15, g = tid_l >> 4;
             const int gx = tl.p0x + g;
 #pragma unroll
@@ -329,6 +332,8 @@ extern "C" int tsod_stem_fp16x2(const tsod_stem_desc *d, const float *x, const v
     // persistent workgroups, two per CU; every workgroup gets the same number of tiles when that is possible (a grid of ceil(tiles / rounds))
     const int64_t slots = 2 * (int64_t)cus, rounds = (tiles + slots - 1) / slots;
     const int64_t grid = (tiles + rounds - 1) / rounds;
+    static const int dbg = [] { const char *e = getenv("TSOD_STEM_DBG"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg;
     hipLaunchKernelGGL(stem_kernel, dim3((unsigned)grid), dim3(256), 0, tsod_stream(stream), p);
     return tsod_launch_status();
 }
