@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip_ops
-from .._ffi import TsodError, require_cuda
+from .._ffi import TsodError, require_cuda, stream_ptr
 from .classify import HarNetRoIHead
 from .rpn import RegionProposalNetwork
 from ..models.hardnet import HarDNetFeatureExtraction, HarNetClassifier
@@ -173,12 +173,7 @@ class FasterRCNN(nn.Module):
             can_stem = hasattr(ext, "conv1") and hasattr(ext, "set_fuse_stem") and 2 in tuple(precisions) and bool(fuse_stem)
             stem = False
             if hasattr(ext, "set_fuse_stem"):
-                # the stem's structure first (it is no tiled GEMM: nothing of the tables depends on it, but every later timing runs
-                # on the structure that will be served)
-                ext.set_fuse_stem(False)
-                if can_stem:
-                    stem = fuse_stem is True or self._stem_pays(example, verbose)
-                    ext.set_fuse_stem(stem)
+                ext.set_fuse_stem(False)                            # (the three-launch stem's conv1 gets its best kernel first)
             if can_fuse:
                 ext.set_fuse_bottleneck(False)                      # every layer first gets its own best kernel
             self(example)                                           # builds the plan; leaves real activations (and range words) behind
@@ -205,6 +200,14 @@ class FasterRCNN(nn.Module):
                     self(example)
                     plan = ext._plan_for(example)
                     plan.import_tiles(table[want[0]])
+            if can_stem:
+                # the stem's structure: the tuned three launches (layout pass, conv1, max pool) against the one launch
+                stem = self._stem_pays(example, plan, verbose) or fuse_stem is True
+                ext.set_fuse_stem(stem)                             # (the timing above dropped the owner's plans: rebuild either way)
+                self(example)
+                plan = ext._plan_for(example)
+                plan.import_tiles_by_name(table[want[0]])
+                table[want[0]] = plan.export_tiles()
             for sched in want[1:]:
                 table[sched] = tune_schedule(plan, sched)
             plan.import_tiles(table.get("serial") or table["in_flight"])
@@ -215,31 +218,39 @@ class FasterRCNN(nn.Module):
                 table["heads"] = self.head_choices()
         return table
 
-    def _stem_pays(self, example, verbose=False, reps=10) -> bool:
-        """HIP-event time of the backbone's forward (input step + every launch of its plan, cost-model tiles) with the one-launch
-        stem against the three-launch one: the structures differ only in the stem, so the difference is the stem's."""
+    def _stem_pays(self, example, plan, verbose=False, reps=20) -> bool:
+        """HIP-event time of the stem alone, back to back: the three launches of ``plan`` (layout pass + its tuned conv1 + max
+        pool) against the one launch of a plan built with ``fuse_stem`` (the rest of the backbone is the same either way)."""
         from ..engine import stage_input
-        ext, times = self.extractor, {}
-        for on in (False, True):
-            ext.set_fuse_stem(on)
-            ext.forward_nhwc(example)
-            plan = ext._plan_for(example)
-            if on and plan.stem_step is None:                       # (a backbone whose stem the kernel does not cover)
-                return False
+        ext = self.extractor
+
+        def head_time(pl):
+            n = 1 if pl.stem_step is not None else 2                # leading launches of the plan that belong to the stem
+            s = stream_ptr()
+            for _ in range(2):
+                stage_input(pl, example)
+                for fn, args in pl.steps[:n]:
+                    fn(*args, s)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            stage_input(plan, example)
-            plan.launch()
             e0.record()
             for _ in range(reps):
-                stage_input(plan, example)
-                plan.launch()
+                stage_input(pl, example)
+                for fn, args in pl.steps[:n]:
+                    fn(*args, s)
             e1.record()
             e1.synchronize()
-            times[on] = e0.elapsed_time(e1) / reps
+            return e0.elapsed_time(e1) / reps
+        t3 = head_time(plan)
+        ext.set_fuse_stem(True)
+        ext.forward_nhwc(example)
+        pf = ext._plan_for(example)
+        t1 = head_time(pf) if pf.stem_step is not None else float("inf")   # (inf: a backbone whose stem the kernel does not cover)
+        ext.set_fuse_stem(False)                                    # (the caller switches; plans of both structures stay cached)
+        ext.forward_nhwc(example)
         if verbose:
-            print(f"  one-launch stem: {times[True] * 1e3:.1f} us per backbone pass against {times[False] * 1e3:.1f} us -> "
-                  f"{'one launch' if times[True] < times[False] else 'three launches'}")
-        return times[True] < times[False]
+            print(f"  one-launch stem: {t1 * 1e3:.1f} us against {t3 * 1e3:.1f} us for layout pass + conv1 + max pool -> "
+                  f"{'one launch' if t1 < t3 else 'three launches'}")
+        return t1 < t3
 
     def import_tuning(self, table, example, schedule="serial", slot=0):
         """Pin a table made by ``tune`` (same model, same input geometry; e.g. rank 0's on every rank) in the plan of ``slot``."""
