@@ -265,7 +265,7 @@ def test_fp16x2_host_side_choices():
     from two_stage_object_detection_amd import _ffi
     from two_stage_object_detection_amd.engine import FP16X2_A_SCALE_EXP, fp16x2_activation_exp
     from two_stage_object_detection_amd.hip_ops import fp16x2_weight_scale_exp
-    assert set(_ffi.FP16X2_TILE_IDS) == (set(_ffi.BF16X3_TILE_IDS) - {18, 20}) | {23, 1, 2, 4} and 22 in _ffi.FP16X2_TILE_IDS   # (d192x128 and the two-stage tiles: fp16x2 only)
+    assert set(_ffi.FP16X2_TILE_IDS) == (set(_ffi.BF16X3_TILE_IDS) - {18, 20}) | {23} and 22 in _ffi.FP16X2_TILE_IDS   # (d192x128: fp16x2 only)
     assert _ffi.PREC_NAMES[_ffi.PREC_FP16X2] == "fp16x2" and FP16X2_A_SCALE_EXP == 4
     for m in (1e-3, 0.7, 100.0, 4093.0, 3e4, 1e9):
         e = fp16x2_activation_exp(m)

@@ -27,9 +27,7 @@ PREC_F32, PREC_BF16X3, PREC_FP16X2 = 0, 1, 2
 PREC_NAMES = {0: "f32", 1: "bf16x3", 2: "fp16x2"}
 DMA_TILE_IDS = (17, 18, 19, 20, 21, 22, 23)                         # through LDS-DMA (23: fp16x2 only): one channel segment, Cin % 16 / % 32 == 0, bf16x3 ONLY
 BF16X3_TILE_IDS = (3, 8, 9, 10, 14, 15, 16) + tuple(t for t in DMA_TILE_IDS if t != 23)   # tiles that exist as bf16x3 variants (include/tsod.h)
-# fp16x2: every bf16x3 tile but the 64-row LDS-DMA ones, + d192x128, + the two-stage register-staged tiles 128x128 / 128x64 / 64x128
-# (two fp16 planes per operand fit two LDS stages where three bf16 planes do not)
-FP16X2_TILE_IDS = (1, 2, 4) + tuple(t for t in BF16X3_TILE_IDS if t not in (18, 20)) + (23,)
+FP16X2_TILE_IDS = tuple(t for t in BF16X3_TILE_IDS if t not in (18, 20)) + (23,)   # fp16x2: every bf16x3 tile but the 64-row LDS-DMA ones, + d192x128
 
 
 class TsodError(RuntimeError):

@@ -1875,16 +1875,14 @@ const TileInfo kTiles[TSOD_TILE_COUNT] = {
 // workgroups per CU: the f32 figure (VGPR / LDS bound), for bf16x3 additionally capped by its larger LDS footprint
 // tiles that exist in the fp16x2 arithmetic: the register-staged bf16x3 tiles and d128x128k32
 bool fp16x2_tile(int t) {   // (the 64-row LDS-DMA tiles would need six DMA slots in a 12-MFMA phase: not built)
-    // (+ the two-stage register-staged tiles 128x128 / 128x64 / 64x128: two fp16 planes per operand fit two LDS stages where three bf16
-    //  planes do not)
     return t == TSOD_TILE_D128x128_K32 || t == TSOD_TILE_D128x128 || t == TSOD_TILE_D256x128 || t == TSOD_TILE_D128x256 || t == TSOD_TILE_D192x128 ||
-           t == TSOD_TILE_128x128 || t == TSOD_TILE_128x64 || t == TSOD_TILE_64x128 || (kTiles[t].bf16x3 && !kTiles[t].dma);
+           (kTiles[t].bf16x3 && !kTiles[t].dma);
 }
 
 int residency(int tile, int prec) {
     const TileInfo &t = kTiles[tile];
     if (!prec) return t.resident;
-    const int lds = t.dma ? t.nbuf * dma_stage_bytes(t.bm, t.bk, t.bn) : t.nbuf * (prec == TSOD_PREC_FP16X2 ? 2 : 3) * (t.bm + t.bn) * (t.bk / 2) * 4;
+    const int lds = t.dma ? t.nbuf * dma_stage_bytes(t.bm, t.bk, t.bn) : t.nbuf * 3 * (t.bm + t.bn) * (t.bk / 2) * 4;
     const int fit = 160 * 1024 / lds;
     return fit < t.resident ? (fit < 1 ? 1 : fit) : t.resident;
 }
@@ -2242,9 +2240,6 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
             case TSOD_TILE_128x64_S1: launch_tile<128, 64, 64, 32, 4, 1, 32, 2>(p, sc.grid, s); break;
             case TSOD_TILE_64x128_S1: launch_tile<64, 128, 32, 64, 4, 1, 32, 2>(p, sc.grid, s); break;
             case TSOD_TILE_128x128_S1: launch_tile<128, 128, 64, 64, 2, 1, 32, 2>(p, sc.grid, s); break;
-            case TSOD_TILE_128x128: launch_tile<128, 128, 64, 32, 2, 2, 32, 2>(p, sc.grid, s); break;      // (eight waves of 64 x 32: four of 64 x 64 spill)
-            case TSOD_TILE_128x64: launch_tile<128, 64, 64, 32, 2, 2, 32, 2>(p, sc.grid, s); break;
-            case TSOD_TILE_64x128: launch_tile<64, 128, 32, 64, 2, 2, 32, 2>(p, sc.grid, s); break;
             case TSOD_TILE_D128x128_K32: launch_dma_tile<128, 32, 2, 3, 1, 2>(p, sc.grid, s); break;
             case TSOD_TILE_D128x128: launch_dma_tile<128, 16, 1, 4, 1, 2>(p, sc.grid, s); break;
             case TSOD_TILE_D256x128: launch_dma_tile<256, 16, 1, 4, 1, 2>(p, sc.grid, s); break;
