@@ -1017,3 +1017,43 @@ def test_stem_fused_matches_the_f64_stem(ops, dev, N, H, W, gain):
     xbad[0, 1, H // 2, W // 3] = float("nan")
     ops.stem_fused(xbad, wfrag, e, bn, slope, range_flag=flag)
     assert int(flag.item()) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,segs,Cout", [
+    (2, 9, 11, [(36, 24), (4, 20)], 20),                                # K = 44: three 16-k steps, the last with 12 live channels
+    (1, 37, 53, [(0, 64), (200, 40), (96, 68), (320, 16)], 136),        # K = 188 over four slices of a 340-channel buffer, two column tiles
+    (2, 50, 84, [(8, 320), (400, 196), (700, 116), (900, 68), (1000, 40)], 336),   # HarDNet-68's base.11.layers.15 shape: K = 740
+])
+def test_conv_fp16x2_lds_dma_over_channel_segments(ops, dev, N, H, W, segs, Cout):
+    """conv_dma_kernel<..., CHAN>: a 1x1 conv over SEVERAL channel segments of a wider NHWC buffer (HarDNet's concatenated inputs) on
+    the LDS-DMA tiles in fp16x2 - every tile, whole tiles / K-slices / hybrid, K no multiple of the K-step, range words - against the
+    f64 CPU conv, and the same bits as the register-staged kernel's K order allows (same bar).  The balanced schedule has no such
+    instantiation and is refused; bf16x3 keeps these layers off the LDS-DMA tiles."""
+    from two_stage_object_detection_amd._ffi import TsodError
+    P = max(o + n for o, n in segs) + 4
+    K = sum(n for _, n in segs)
+    g = torch.Generator().manual_seed(91 + K)
+    x = torch.randn(N, P, H, W, generator=g)
+    x = torch.maximum(x, 0.25 * x)
+    w = torch.randn(Cout, K, 1, 1, generator=g) / math.sqrt(K)
+    res = torch.randn(N, Cout, H, W, generator=g)
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    y = F.conv2d(torch.cat([x[:, o:o + n] for o, n in segs], dim=1).double(), w.double()) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    y = y + res.double()
+    ref = (torch.clamp(y, min=0) + 0.25 * torch.clamp(y, max=0)).float()
+    xn, wp, rn = ops.nchw_to_nhwc(x.to(dev)), ops.pack_conv_weight(w.to(dev)), ops.nchw_to_nhwc(res.to(dev))
+    words = ops.absmax(xn, ops.new_amax_words(dev, 1))
+    tol = (3e-6 * math.sqrt(K) + 1e-5) * max(1.0, float(ref.abs().max()) / 4.0)
+    kw = dict(segs=segs, scale=scale.to(dev), shift=shift.to(dev), residual=rn, act=1, slope=0.25, precision=2)
+    for tile in (17, 19, 21, 22, 23):
+        for split in (1, 2, -1):
+            out = ops.conv2d_nhwc(xn, wp, tile=tile, split_k=split, amax_in=words, **kw)
+            err = (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item()
+            assert err <= tol, (tile, split, err, tol)
+    out = ops.conv2d_nhwc(xn, wp, tile=22, split_k=1, a_scale_exp=6, **kw)          # static exponent
+    assert (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item() <= tol
+    with pytest.raises(TsodError, match="unsupported|UNSUPPORTED"):
+        ops.conv2d_nhwc(xn, wp, tile=22, split_k=-2, amax_in=words, **kw)
+    with pytest.raises(TsodError, match="unsupported|UNSUPPORTED"):
+        ops.conv2d_nhwc(xn, wp, tile=22, split_k=1, **{**kw, "precision": 1})

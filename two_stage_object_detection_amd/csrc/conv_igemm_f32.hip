@@ -82,6 +82,7 @@ struct ConvParams {
     const float *in2;
     unsigned in2_bytes;
     int K1, c2, in2_pitch, in2_off, stride2, H2, W2;
+    int chan_tab;                 // LDS-DMA tiles: 1 = a 1x1 filter over SEVERAL channel segments (conv_dma_kernel<..., CHAN = true>)
     int pointwise_tab;            // 1: a 1x1 filter (no padding, no second source) over several channel segments (HarDNet's concatenated
                                   //    inputs) with K <= 4 * kChanTab: the channel offset of every 4-k chunk comes from a table the workgroup
                                   //    builds in LDS once, instead of a select chain over the segments + the k -> (tap, channel) arithmetic
@@ -985,7 +986,8 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN), MIN_WAVES) conv_ig
 //     inside a stage (each owns one 16-k chunk; the halves are exchanged through LDS before the epilogue, every wave then
 //     finishing 32 x 64).  One phase per stage and wave; an S-deep ring of stages; vmcnt / lgkmcnt counted by hand (the
 //     compiler sees none of these memory operations; what it must not do is keep LDS reads of its own pending in the loop).
-// Requires one channel segment, Cin % BK == 0 (a stage lies inside one filter tap) and, with a second source, K1 % BK == 0.
+// Requires one channel segment, Cin % BK == 0 (a stage lies inside one filter tap) and, with a second source, K1 % BK == 0 - or
+// (fp16x2, CHAN) a 1x1 filter over several segments, where every 16-byte chunk of a stage has its own place (chunk table).
 // Measurements and the instruction-level findings behind this layout: DESIGN.md 4.3, scripts/micro/bf16x3_dma_probe.hip.
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 #ifdef TSOD_DIAG_NODMA
@@ -1023,6 +1025,7 @@ __device__ __forceinline__ void dma4(unsigned voff, v4i32 rsrc, unsigned lds_dst
 template <int N, typename T> __device__ __forceinline__ void wait_lgkm_for(T &x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void lds_read4(unsigned &out, unsigned addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(out) : "v"(addr) : "memory"); }
 template <int OFF, typename T> __device__ __forceinline__ void lds_read16(T &out, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(out) : "v"(addr), "n"(OFF) : "memory");
 }
@@ -1153,13 +1156,18 @@ constexpr int dma_stage_bytes(int bm, int bk, int bn = 128, int npl = 3) { retur
 constexpr int dma_wgs_per_cu(int bm, int bk, int waves_k, int s, int waves_n, int npl) {
     return (2 * s * dma_stage_bytes(bm, bk, 128 * waves_n, npl) <= 160 * 1024 && 2 * (bm / 32) * waves_k * waves_n <= 8) ? 2 : 1;
 }
+constexpr int kDmaChanEntries = 640;  // CHAN: 16-byte chunks of one workgroup's K range + ring (K <= 2048: 512 + 8 slots x 8 stages)
 constexpr int kDmaTabEntries = 640;   // K-steps of one workgroup's K range + ring depth + 1 (tile_ok_for keeps K / bk + 8 below it)
 constexpr unsigned kDmaSecondBit = 0x80000000u;   // validity-mask bit of the second source's 1x1 tap (filter taps use bits 0..30)
 
 // WAVES_N = 2: two columns of waves, BN = 256 - both read (and split) the same activation rows, each its own 128 output
 // channels: more FLOP per byte fetched from beyond the CU (the activation stage is shared) at the same 128-row granularity
 // NPL = pieces per operand: 3 = bf16x3 (six piece products per k chunk), 2 = fp16x2 (three)
-template <int BM, int BK, int WAVES_K, int S, bool BALANCED, int WAVES_N = 1, int NPL = 3>
+// CHAN: a 1x1 filter over SEVERAL channel segments (HarDNet's concatenated inputs; K = the segments' channels in order, any
+// multiple of 4): the 16-byte chunk a lane fetches for a stage lies wherever its segment lies, so besides the stage table there
+// is a CHUNK table in LDS - byte offset inside the pixel of every 4-channel chunk of the K range (out-of-range past K: zeros) -
+// and a lane reads its chunk's entry beside the stage's (one ds_read_b32 per activation piece and phase).
+template <int BM, int BK, int WAVES_K, int S, bool BALANCED, int WAVES_N = 1, int NPL = 3, bool CHAN = false>
 __global__ void __launch_bounds__((BM / 32) * WAVES_K * WAVES_N * 64, dma_wgs_per_cu(BM, BK, WAVES_K, S, WAVES_N, NPL))
 conv_dma_kernel(const ConvParams p) {
     constexpr int BN = 128 * WAVES_N, TN = 4, WAVES_M = BM / 32, WAVES = WAVES_M * WAVES_K * WAVES_N, THREADS = WAVES * 64;
@@ -1192,7 +1200,9 @@ conv_dma_kernel(const ConvParams p) {
     // fp16x2: 2 x 256 bytes behind the table for the range words of the two sources (the bf16x3 d128x128 ring fills the LDS of two
     // workgroups per CU exactly and has no use for them)
     constexpr int AMAX_OFF = TAB_OFF + (TABLE ? TAB_BYTES : 0), AMAX_LDS = NPL == 2 ? 512 : 0;
-    __shared__ __align__(16) unsigned char lds[AMAX_OFF + AMAX_LDS];
+    constexpr int CH_OFF = AMAX_OFF + AMAX_LDS, CH_BYTES = CHAN ? kDmaChanEntries * 4 : 0;
+    static_assert(!CHAN || (TABLE && NPL == 2 && !BALANCED && LB_WGS * (CH_OFF + CH_BYTES) <= 160 * 1024), "the chunk table rides beside the stage table");
+    __shared__ __align__(16) unsigned char lds[CH_OFF + CH_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WAVES_M, wk = (wave / WAVES_M) % WAVES_K, wn = wave / (WAVES_M * WAVES_K);
@@ -1264,26 +1274,28 @@ conv_dma_kernel(const ConvParams p) {
     v4i32 rs_in = dma_rsrc(p.in, p.in_bytes), rs_w = dma_rsrc(p.w, p.w_bytes);
     v4i32 rs_in2 = dma_rsrc(p.in2 ? p.in2 : p.in, p.in2 ? p.in2_bytes : 0u);
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)lds;
-    const int kgroups = p.K / 8;
+    const int kgroups = (p.K + 7) / 8;                            // (the weight image pads K to whole 8-k groups)
 
     // ---- this wave's DMA pieces: q = WAVES * i + wave; piece i is an A piece for i < PA_W (1 or 2 for every tile shape; the
     // rows' state in two named structs: an array of them ends up in scratch memory behind the source select below, and a
     // scratch access is a VMEM operation that would sit in the middle of the hand-counted vmcnt)
     static_assert(PA_W == 1 || PA_W == 2, "one or two A pieces per wave and stage");
-    struct ARow { unsigned base, base2; int ih0, iw0; unsigned mask; };   // mask: bit t = filter tap t lies inside the image for this row
+    struct ARow { unsigned base, base2; int ih0, iw0; unsigned mask; int lslot; };   // mask: bit t = filter tap t lies inside the image for this row; lslot (CHAN): the 16-byte chunk of a stage this lane fetches
     unsigned b_voff[P - PA_W], ldst[P];
     auto make_arow = [&](int i) {
         ARow ar;
         const int q = WAVES * i + wave;
         const int row = q * A_RPP + lane / A_SLOTS, phys = lane % A_SLOTS;
-        const unsigned lofs = (unsigned)((phys ^ ((row / A_RPL) & (A_SLOTS - 1))) * 16);
+        ar.lslot = phys ^ ((row / A_RPL) & (A_SLOTS - 1));
+        // (CHAN: the chunk's place inside the pixel comes from the chunk table, neither the first segment's offset nor the slot's)
+        const unsigned lofs = CHAN ? 0u : (unsigned)(ar.lslot * 16);
         const int m = m0 + row;
         if (m < p.M) {
             const int ow = m % p.OW, t = m / p.OW, oh = t % p.OH, img = t / p.OH;
             ar.ih0 = oh * p.stride - p.pad_h;
             ar.iw0 = ow * p.stride - p.pad_w;
             // may wrap below zero for border rows; adding a valid tap's delta brings it back in range
-            ar.base = (unsigned)((((long)img * p.H + ar.ih0) * p.W + ar.iw0) * p.in_pitch + p.seg_off[0]) * 4u + lofs;
+            ar.base = (unsigned)((((long)img * p.H + ar.ih0) * p.W + ar.iw0) * p.in_pitch + (CHAN ? 0 : p.seg_off[0])) * 4u + lofs;
             ar.base2 = p.c2 > 0 ? (unsigned)((((long)img * p.H2 + oh * p.stride2) * p.W2 + ow * p.stride2) * p.in2_pitch + p.in2_off) * 4u + lofs
                                 : kOOB;
         } else {
@@ -1343,7 +1355,7 @@ conv_dma_kernel(const ConvParams p) {
     unsigned u_delta, u_woff;
     bool u_second;
     v4i32 u_rs_a = rs_in, u_rs_w = rs_w;
-    const int k1_steps = p.K1 / BK;                               // (K1 % BK == 0: tile_ok_for)
+    const int k1_steps = CHAN ? 0x7fffffff : p.K1 / BK;          // (K1 % BK == 0: tile_ok_for; CHAN: no second source, K any multiple of 4)
     auto stage_state = [&]() {
 #ifdef TSOD_DIAG_NODMA
         const bool live = u_kt < kt_begin + nodma_steps;         // timing probe only (make nodma): null DMAs after the ring's first fill
@@ -1387,12 +1399,21 @@ conv_dma_kernel(const ConvParams p) {
     unsigned t_woff = 0;
     bool t_second = false;
     v4i32 t_rs_a = rs_in, t_rs_w = rs_w;
+    unsigned t_cd[2] = {0u, 0u};                                  // CHAN: the chunk-table entries of this lane's activation pieces
     auto issue_piece = [&](auto I, auto FROM_TABLE, unsigned slot_off) {
         constexpr int i = decltype(I)::value;
         constexpr bool from_table = decltype(FROM_TABLE)::value;
         if constexpr (i < PA_W) {
             const ARow ar = i == 0 ? ar0 : ar1;
-            if constexpr (from_table) {
+            if constexpr (CHAN && from_table) {
+                const bool ok = (ar.mask & t_e.z) != 0 && t_cd[i] != kOOB;
+                dma16(ok ? ar.base + t_cd[i] : kOOB, t_rs_a, 0u, ldst[i], slot_off);
+            } else if constexpr (CHAN) {
+                // the ring's first fill (no tables yet): this lane's chunk of stage u_kt straight from the segment list
+                const int k = u_kt * BK + 4 * ar.lslot;
+                const bool ok = ar.ih0 >= 0 && k < p.K;            // (1x1, no padding: a row < M is inside the image)
+                dma16(ok ? ar.base + (unsigned)(seg_channel(p, k) * 4) : kOOB, u_rs_a, 0u, ldst[i], slot_off);
+            } else if constexpr (from_table) {
                 // a row fetches when the stage's tap lies inside the image for it (rows past M and every row of a stage past the
                 // K range have no bit in common with the entry: the out-of-range offset, no memory traffic, zeros written)
                 const bool ok = (ar.mask & t_e.z) != 0;
@@ -1452,6 +1473,9 @@ conv_dma_kernel(const ConvParams p) {
     // wave's DMA pieces of the stage being issued go out one per few gaps.  `soff` = byte offset of the ring slot that is read.
     // `tab_ptr` (TABLE): LDS address of the table entry of the stage this phase issues; it moves on by one entry per phase
     unsigned tab_ptr = lds0 + TAB_OFF + S * 16;
+    // (CHAN) LDS addresses of this lane's chunk-table entries for the stage a phase issues: one per activation piece, moving on by a
+    // stage's A_SLOTS entries per phase
+    unsigned ch_ptr0 = lds0 + CH_OFF + (unsigned)((S * A_SLOTS + ar0.lslot) * 4), ch_ptr1 = lds0 + CH_OFF + (unsigned)((S * A_SLOTS + ar1.lslot) * 4);
     auto phase = [&](const Frags &cur, Frags &nxt, unsigned soff, int dma_slot) {
         float4 raw0, raw1;
         unsigned hh[4], mm[4], ll[4];
@@ -1467,6 +1491,12 @@ conv_dma_kernel(const ConvParams p) {
         if constexpr (TABLE) {
             lds_read16<0>(t_e, tab_ptr);
             tab_ptr += 16;
+            if constexpr (CHAN) {                                // (issued before the raw rows: the counted wait below covers them too)
+                lds_read4(t_cd[0], ch_ptr0);
+                if constexpr (PA_W == 2) lds_read4(t_cd[1], ch_ptr1);
+                ch_ptr0 += A_SLOTS * 4;
+                ch_ptr1 += A_SLOTS * 4;
+            }
         }
         lds_read16<0>(raw0, a_addr[0] + soff);
         lds_read16<0>(raw1, a_addr[1] + soff);
@@ -1476,6 +1506,9 @@ conv_dma_kernel(const ConvParams p) {
         gap2_read<0>(TSOD_MF2(3), nxt.b[3][0], b_addr[3] + soff);
         if constexpr (TABLE) {
             wait_lgkm_for<4>(t_e);
+            // (CHAN: the chunk entries were read by asm statements too - what is computed from them must follow the wait, and only a
+            //  statement the compiler cannot move ties that down)
+            if constexpr (CHAN) asm volatile("" : "+v"(t_cd[0]), "+v"(t_cd[1]));
             const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)t_e.w);
             t_woff = (unsigned)__builtin_amdgcn_readfirstlane((int)t_e.y);
             t_second = (flags & 1u) != 0;
@@ -1637,6 +1670,14 @@ conv_dma_kernel(const ConvParams p) {
                     }
                 }
                 *reinterpret_cast<u32x4 *>(lds + TAB_OFF + j * 16) = e;
+            }
+            if constexpr (CHAN) {
+                // the chunk table of the same steps: byte offset inside the pixel of the 4 channels k .. k + 3 (out of range past K or
+                // past this K range: zeros land)
+                for (int idx = tid; idx < (nk + S + 1) * A_SLOTS; idx += THREADS) {
+                    const int step = kt_begin + idx / A_SLOTS, k = step * BK + 4 * (idx % A_SLOTS);
+                    *reinterpret_cast<unsigned *>(lds + CH_OFF + idx * 4) = (step < kt_end && k < p.K) ? (unsigned)(seg_channel(p, k) * 4) : kOOB;
+                }
             }
         }
         wait_vm<(S - 1) * P>();
@@ -1938,11 +1979,20 @@ int desc_k(const tsod_conv2d_desc *d) { return d->KH * d->KW * desc_cin(d) + (d-
 // second source (the uniform-tap loader has no k < K mask: a K-step that ran past in2's c2 channels would read the next
 // pixel's channels and the next weight row); the LDS-DMA tiles need that always (a stage lies inside one filter tap of one
 // channel segment, K is whole stages)
+// conv_dma_kernel<..., CHAN = true>: a 1x1 filter (stride 1, no padding, no second source) over several channel segments, fp16x2
+bool dma_chan_case(const tsod_conv2d_desc *d) {
+    return d->precision == TSOD_PREC_FP16X2 && d->n_seg > 1 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 &&
+           d->c2 <= 0;
+}
+
 bool tile_ok_for(const tsod_conv2d_desc *d, int tile) {
     const int bk = kTiles[tile].bk;
-    if (kTiles[tile].dma)
+    if (kTiles[tile].dma) {
+        if (dma_chan_case(d))                    // 1x1 over several segments: the fp16x2 instantiations carry a chunk table (K <= 2048)
+            return desc_k(d) <= 2048 && desc_k(d) / bk + 9 <= kDmaTabEntries;
         return d->n_seg == 1 && desc_cin(d) % bk == 0 && (d->c2 <= 0 || d->c2 % bk == 0) &&
                d->KH * d->KW <= 31 && desc_k(d) / bk + 8 <= kDmaTabEntries;   // (the stage table: one mask bit per tap, K range + ring)
+    }
     if (d->c2 <= 0) return true;
     return desc_cin(d) % bk == 0 && (d->KH * d->KW * desc_cin(d)) % bk == 0 && d->c2 % bk == 0;
 }
@@ -2013,7 +2063,8 @@ Sched make_sched(const tsod_conv2d_desc *d, int tile, int mode) {
         int64_t q = tsod_cdiv(total, slots);
         if (q < 4) q = 4;                                         // a workgroup's prologue / epilogue need some K loop to pay for
         const int64_t grid = tsod_cdiv(total, q);
-        if (kTiles[tile].dma && q < INT_MAX && (size_t)s.tiles * sizeof(int) <= kTicketBytes) {
+        // (the multi-segment 1x1 form of the LDS-DMA kernel has no balanced instantiation)
+        if (kTiles[tile].dma && !dma_chan_case(d) && q < INT_MAX && (size_t)s.tiles * sizeof(int) <= kTicketBytes) {
             s.sk_q = (int)q; s.grid = (int)grid;
             s.split = 1; s.ksteps_per_split = ksteps; s.dp_tiles = 0; s.rem_tiles = s.tiles;
             s.ticket_bytes = kTicketBytes;
@@ -2107,6 +2158,12 @@ Sched resolve(const tsod_conv2d_desc *d) {
 
 template <int BM, int BK, int WAVES_K, int S, int WAVES_N = 1, int NPL = 3>
 void launch_dma_tile(const ConvParams &p, int grid, hipStream_t s) {
+    if constexpr (NPL == 2) {
+        if (p.chan_tab) {                                         // 1x1 over several channel segments (never balanced: make_sched)
+            hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S, false, WAVES_N, NPL, true>), dim3(grid), dim3((BM / 32) * WAVES_K * WAVES_N * 64), 0, s, p);
+            return;
+        }
+    }
     if (p.sk_q > 0)
         hipLaunchKernelGGL((conv_dma_kernel<BM, BK, WAVES_K, S, true, WAVES_N, NPL>), dim3(grid), dim3((BM / 32) * WAVES_K * WAVES_N * 64), 0, s, p);
     else
@@ -2204,6 +2261,7 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
     TSOD_REQUIRE(sc.cost < 1e299, TSOD_ERR_UNSUPPORTED);        // the named tile cannot run this problem (LDS-DMA tiles: tile_ok_for)
     p.uniform_tap = (d->n_seg == 1 && p.Cin % kTiles[sc.tile].bk == 0) ? 1 : 0;
     static const bool no_chan_tab = getenv("TSOD_NO_CHAN_TAB") != nullptr;     // diagnostic: the arithmetic loader for every layer
+    p.chan_tab = (kTiles[sc.tile].dma && dma_chan_case(d)) ? 1 : 0;
     p.pointwise_tab = (!no_chan_tab && !p.uniform_tap && !kTiles[sc.tile].dma && d->KH == 1 && d->KW == 1 && d->pad_h == 0 && d->pad_w == 0 && d->stride == 1 &&
                        p.c2 == 0 && p.K <= 4 * kChanTab) ? 1 : 0;
     TSOD_REQUIRE(p.c2 == 0 || (p.uniform_tap && p.K1 % kTiles[sc.tile].bk == 0 && p.c2 % kTiles[sc.tile].bk == 0), TSOD_ERR_UNSUPPORTED);
