@@ -40,8 +40,11 @@ __device__ __forceinline__ float4 load_box(const float *__restrict__ base, int s
 }
 
 // LABEL_COL >= 0: column of the row that holds the class; pairs of different classes never suppress each other.
+// One workgroup = one 64 x 64 block of pairs, FOUR waves: wave w tests the rows against columns 16 w .. 16 w + 15, so a lane's chain
+// is 16 IoUs instead of 64 (the kernel is bound by that chain - one round of resident waves either way: 13.6 -> 7 us at 3000 boxes),
+// and the four 16-bit parts of a row's word meet in LDS.  The same expressions on the same operands: bit-exact.
 template <int STRIDE, int LABEL_COL>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 nms_mask_kernel(const float *__restrict__ boxes, const int *__restrict__ counts, int n_max, int words, float thr,
                 unsigned long long *__restrict__ mask) {
     constexpr int stride = STRIDE, label_col = LABEL_COL;
@@ -51,24 +54,36 @@ nms_mask_kernel(const float *__restrict__ boxes, const int *__restrict__ counts,
     if (rb * 64 >= n) return;  // rows past n are never read either
     __shared__ float4 col[64];
     __shared__ float col_label[64];
-    const int lane = threadIdx.x;
+    __shared__ unsigned part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *bx = boxes + (long)b * n_max * stride;
-    const int cj = cb * 64 + lane;
-    col[lane] = cj < n ? load_box(bx, stride, cj) : make_float4(0.f, 0.f, 0.f, 0.f);
-    col_label[lane] = (label_col >= 0 && cj < n) ? bx[(long)cj * stride + label_col] : 0.f;
-    __syncthreads();
+    if (wave == 0) {
+        const int cj = cb * 64 + lane;
+        col[lane] = cj < n ? load_box(bx, stride, cj) : make_float4(0.f, 0.f, 0.f, 0.f);
+        col_label[lane] = (label_col >= 0 && cj < n) ? bx[(long)cj * stride + label_col] : 0.f;
+    }
     const int i = rb * 64 + lane;
-    unsigned long long bits = 0;
+    float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+    float my_label = 0.f;
     if (i < n) {
-        const float4 me = load_box(bx, stride, i);
-        const float my_label = label_col >= 0 ? bx[(long)i * stride + label_col] : 0.f;
+        me = load_box(bx, stride, i);
+        if (label_col >= 0) my_label = bx[(long)i * stride + label_col];
+    }
+    __syncthreads();
+    unsigned bits = 0;
+    if (i < n) {
         const int jmax = min(64, n - cb * 64);
-        for (int j = 0; j < jmax; ++j) {
-            const int gj = cb * 64 + j;
-            if (gj > i && (label_col < 0 || col_label[j] == my_label) && iou_nms(me, col[j]) > thr) bits |= 1ull << j;
+#pragma unroll 4
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * wave + jj, gj = cb * 64 + j;
+            if (j < jmax && gj > i && (label_col < 0 || col_label[j] == my_label) && iou_nms(me, col[j]) > thr) bits |= 1u << jj;
         }
     }
-    if (i < n_max) mask[((long)b * n_max + i) * words + cb] = bits;
+    part[wave][lane] = bits;
+    __syncthreads();
+    if (wave == 0 && i < n_max)
+        mask[((long)b * n_max + i) * words + cb] = (unsigned long long)part[0][lane] | ((unsigned long long)part[1][lane] << 16) |
+                                                   ((unsigned long long)part[2][lane] << 32) | ((unsigned long long)part[3][lane] << 48);
 }
 
 __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
@@ -200,13 +215,13 @@ int launch_nms(const float *boxes, int stride, int label_col, const int32_t *cou
     unsigned long long *mask = static_cast<unsigned long long *>(workspace);
     hipStream_t s = tsod_stream(stream);
     if (stride == 4)
-        hipLaunchKernelGGL((nms_mask_kernel<4, -1>), dim3(words, words, B), dim3(64), 0, s, boxes, counts, n_max, words,
+        hipLaunchKernelGGL((nms_mask_kernel<4, -1>), dim3(words, words, B), dim3(256), 0, s, boxes, counts, n_max, words,
                            iou_thr, mask);
     else if (label_col >= 0)
-        hipLaunchKernelGGL((nms_mask_kernel<6, 5>), dim3(words, words, B), dim3(64), 0, s, boxes, counts, n_max, words,
+        hipLaunchKernelGGL((nms_mask_kernel<6, 5>), dim3(words, words, B), dim3(256), 0, s, boxes, counts, n_max, words,
                            iou_thr, mask);
     else
-        hipLaunchKernelGGL((nms_mask_kernel<6, -1>), dim3(words, words, B), dim3(64), 0, s, boxes, counts, n_max, words,
+        hipLaunchKernelGGL((nms_mask_kernel<6, -1>), dim3(words, words, B), dim3(256), 0, s, boxes, counts, n_max, words,
                            iou_thr, mask);
     const size_t lds = (size_t)n_post * sizeof(int);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), lds, s, boxes, stride, counts, n_max, words, n_post, mask, keep_idx,
