@@ -602,9 +602,18 @@ def main(argv=None):
             tsod_comm = TsodCommunicator(rank=rank, world=world)      # id from rank 0 over the torch.distributed group
 
         def make_step(server, depth):
+            """One step of the timed loop.  With several steps in flight (the headline) a step is what a server does per request:
+            COLLECT the result of the request that last used the slot (InFlightDetector.result: wait for that step's event, read
+            the slot's range word - host work that overlaps the other slots' kernels), then submit the next one into it.  The
+            serial schedule queues its forwards back to back on one stream (the latency chain of the kernels, no host round trip
+            between two forwards); its results are collected behind the timed region."""
+            collect = depth > 1 and hasattr(server, "_ticket_of")
+
             def step():
+                slot = server._next % depth
+                if collect and server._ticket_of[slot] is not None:
+                    server.result(server._ticket_of[slot])
                 if world > 1:                           # the gather of step i is ordered behind step i on ITS stream
-                    slot = server._next % depth
                     if tsod_comm is not None:
                         return server.submit(after=lambda outs: tsod_comm.all_gather(outs[4], out=gathered[slot]))
                     return server.submit(after=lambda outs: all_gather_detections(
@@ -743,6 +752,8 @@ def main(argv=None):
                                    + (" (BASELINE configs[4]: data-parallel, 8 images per rank)" if world > 1 and B == 8 else ""),
                        "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}",
                        "hip_graph": not args.no_graph, "autotuned_tiles": not args.no_autotune, "steps_in_flight": n_fly,
+                       "timed_step": ("result() of the request that last used the slot (event wait + the slot's range-word read), then submit()"
+                                      if n_fly > 1 else "submit() only: forwards queued back to back on one stream, results collected behind the region"),
                        # the two schedules side by side (value / ms_per_step above = the in-flight one)
                        "images_per_s_in_flight": round(n_gpus * B / (head["ms_per_step"] * 1e-3), 3),
                        "images_per_s_serial": round(n_gpus * B / (serial["ms_per_step"] * 1e-3), 3),

@@ -381,6 +381,48 @@ def test_forward_modes_surface(dev, synth):
         assert det.shape == (1, 300, 6)
 
 
+def test_staged_modes_after_an_fp16x2_choice_of_the_two_head_gemms(dev):
+    """mode = "rpn" / "head" (and rpn.forward / head.forward) on a geometry whose tuned choice for the fused RPN conv and the
+    fused head GEMM is fp16x2: the staged API has no backbone plan whose range words it could scale with, so it measures the
+    range of what it is handed (one tsod_absmax_f32 pass) - it used to raise.  First with the choices pinned by hand, then
+    with whatever FasterRCNN.tune() pins."""
+    from two_stage_object_detection_amd import _ffi
+    from two_stage_object_detection_amd.testing import synthetic_detector
+    model, sd = synthetic_detector("resnet50", num_classes=20, seed=0)
+    model = model.to(dev).eval()
+    x = _img((1, 3, 320, 448))
+    with torch.inference_mode():
+        ref_out, dbg = oracle.detector_forward(sd, x, backbone="resnet50", return_debug=True)
+        feat = dbg["feat"].to(dev)
+        n, _, h, w = feat.shape
+
+        def staged():
+            r = model((feat, tuple(x.shape[1:])), mode="rpn")
+            model.rpn.raise_if_error()
+            assert (r[0].cpu() - dbg["rpn_locs"]).abs().max().item() < 1e-3
+            assert (r[1].cpu() - dbg["rpn_scores"]).abs().max().item() < 1e-3
+            d = (r[2].cpu().unsqueeze(2) - ref_out[2].unsqueeze(1)).abs().amax(-1)
+            assert (d.amin(dim=2) <= 1e-3).float().mean().item() > 0.98
+            cl, sc = model((feat, ref_out[2].to(dev), ref_out[3].to(dev), tuple(x.shape[2:])), mode="head")
+            assert (cl.cpu() - ref_out[0]).abs().max().item() < 1e-3
+            assert (sc.cpu() - ref_out[1]).abs().max().item() < 1e-3
+            assert torch.equal(sc.cpu().argmax(-1), ref_out[1].argmax(-1))
+
+        tile = 3                                                   # 64x64, two LDS stages: exists in every arithmetic
+        assert tile in _ffi.FP16X2_TILE_IDS
+        model.set_head_choices({"rpn": {f"{n}x{h}x{w}": [tile, 1, _ffi.PREC_FP16X2]}, "head": {str(n * 300): [tile, 1, _ffi.PREC_FP16X2]}})
+        staged()
+        # ... and after the public tuning call with fp16x2 as the only arithmetic on offer for the two GEMMs' competitors too
+        table = model.tune(x.to(dev), precisions=(0, 2), schedules=("serial",), in_sequence=0, reps=1, fuse_bottleneck=False,
+                           fuse_stem=False, splits=[1, -1])
+        assert set(table["heads"]) == {"rpn", "head"}
+        staged()
+        out = model(x.to(dev))                                     # the one-call forward still agrees with the oracle
+        model.raise_if_error()
+    from two_stage_object_detection_amd.testing import compare_detector_outputs
+    assert compare_detector_outputs([o.cpu() for o in out], ref_out)["ok"]
+
+
 def test_batches_beyond_the_32bit_offset_range_are_cut_into_image_groups(dev, monkeypatch):
     """The conv kernel uses 32-bit byte offsets; Plan.conv cuts a batch whose tensors exceed the limit into image
     groups.  Forced here with a tiny limit: the grouped plan must reproduce the ungrouped result (to f32 summation-
@@ -464,6 +506,41 @@ def test_in_flight_detector_returns_each_requests_own_result(dev, synth):
             assert torch.equal(a, b), f"ticket {t}"
     with pytest.raises(Exception):
         server.result(0)                                          # slot 0 has been reused since
+
+
+def test_in_flight_detector_blames_the_request_at_fault(dev):
+    """Every in-flight slot reports into a range word of its own: a request with a non-finite pixel raises at ITS result(),
+    whichever ticket is collected first, and the clean requests around it keep their results (one shared word used to hand the
+    error to the first ticket collected and the garbage to the one at fault)."""
+    from two_stage_object_detection_amd._ffi import TsodError
+    from two_stage_object_detection_amd.serving import InFlightDetector
+    from two_stage_object_detection_amd.testing import synthetic_detector
+    model, _ = synthetic_detector("resnet50", num_classes=20, seed=0)
+    model = model.to(dev).eval()
+    model.extractor.set_conv_precision("fp16x2")                  # (the arithmetic that reports non-finite accumulators)
+    xs = [_img((1, 3, 224, 288), seed=70 + i).to(dev) for i in range(3)]
+    bad = xs[1].clone()
+    bad[0, 2, 100, 50] = float("nan")
+    server = InFlightDetector(model, xs[0], depth=3)
+    with torch.inference_mode():
+        want0 = [t.clone() for t in model(xs[0])]
+        want2 = [t.clone() for t in model(xs[2])]
+        model.raise_if_error()
+    ta, tb, tc = server.submit(xs[0]), server.submit(bad), server.submit(xs[2])
+    got_c = server.result(tc)                                     # a clean ticket collected FIRST: no error, its own result
+    for a, b in zip(got_c, want2):
+        assert torch.equal(a, b)
+    with pytest.raises(TsodError, match="non-finite"):
+        server.result(tb)                                         # the one at fault raises ...
+    got_a = server.result(ta)                                     # ... and the other clean one is still handed out
+    for a, b in zip(got_a, want0):
+        assert torch.equal(a, b)
+    t2 = server.submit(xs[1])                                     # the slot is usable again (its word was cleared by the raise)
+    server.result(t2)
+    server.drain()
+    # plans of one owner on one device share the words' tensor; the words belong to the plan's own device
+    plan = model.extractor._plan_for(xs[0], 1)
+    assert plan.range_flag.device == xs[0].device and plan.range_flag.numel() == 1
 
 
 @pytest.mark.parametrize("backbone", ["resnet50", "hardnet39"])

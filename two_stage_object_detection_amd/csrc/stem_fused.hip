@@ -308,7 +308,9 @@ extern "C" int tsod_stem_fp16x2(const tsod_stem_desc *d, const float *x, const v
     TSOD_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->in_layout == TSOD_STEM_NCHW || d->in_layout == TSOD_STEM_NHWC4, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->out_pitch >= 64 && (d->out_pitch & 3) == 0, TSOD_ERR_ALIGNMENT);
-    TSOD_REQUIRE(tsod_aligned16(x) && tsod_aligned16(out) && tsod_aligned16(wfrag) && tsod_aligned16(bn), TSOD_ERR_ALIGNMENT);
+    // (NCHW images are read with 4-byte loads: a batch slice x[i:i+1] of a caller's tensor is as good as the tensor; NHWC4 pixels are 16-byte loads)
+    TSOD_REQUIRE(d->in_layout == TSOD_STEM_NCHW ? (reinterpret_cast<uintptr_t>(x) & 3u) == 0 : tsod_aligned16(x), TSOD_ERR_ALIGNMENT);
+    TSOD_REQUIRE(tsod_aligned16(out) && tsod_aligned16(wfrag) && tsod_aligned16(bn), TSOD_ERR_ALIGNMENT);
     TSOD_REQUIRE((reinterpret_cast<uintptr_t>(d->amax_out) & 63u) == 0, TSOD_ERR_ALIGNMENT);
     const uint64_t in_bytes = (uint64_t)d->N * d->H * d->W * (d->in_layout == TSOD_STEM_NCHW ? 12 : 16);
     TSOD_REQUIRE(in_bytes < 0xFFFFFFF0ull, TSOD_ERR_UNSUPPORTED);            // 32-bit byte offsets into x

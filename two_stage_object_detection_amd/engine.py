@@ -120,8 +120,9 @@ class FusedStep:
     """One tsod_bottleneck_fp16x2 launch of a plan, with what the timing / roofline code asks of a ConvStep."""
     precision = _ffi.PREC_FP16X2
 
-    def __init__(self, name, fn, args, desc, flops, algorithmic_bytes):
+    def __init__(self, name, fn, args, desc, flops, algorithmic_bytes, x=None):
         self.name, self.fn, self.args, self.desc, self.flops, self.algorithmic_bytes = name, fn, args, desc, flops, algorithmic_bytes
+        self.x, self.x2 = x, None            # the activation input (None: the stem, whose pixel scale is each tile's own)
 
 
 def step_precision(st) -> int:
@@ -257,7 +258,8 @@ class Plan:
         self.workspace: torch.Tensor | None = None
         self.graph = None
         # fp16x2 layers OR 1 into this word when a launch ends with non-finite accumulators (include/tsod.h: range_flag);
-        # PlanOwner shares ONE word among all its plans (see _cached_plan): it survives plan eviction and costs one read
+        # a PlanOwner hands its plans one word per (device, in-flight slot) out of a tensor of its own (see _cached_plan): the word
+        # survives plan eviction, and checking all of an owner's words costs one small read per device
         self.range_flag = new_range_flag(self.device)
         self.a_exps: dict = {}               # layer name -> fp16x2 activation exponent (calibrate_fp16x2); the owner shares ONE dict among its plans
         self.flops = 0
@@ -307,7 +309,7 @@ class Plan:
         the forward by now, or what earlier candidates left - make the input's range words describe the bytes that are there, so
         that an fp16x2 candidate is timed on in-range operands like the ones it will meet (non-finite accumulators cost power
         and reports, and would pick the table for the wrong reasons)."""
-        for t, a in ((st.x, st.desc.amax_in), (st.x2, st.desc.amax_in2)):
+        for t, a in ((st.x, getattr(st.desc, "amax_in", None)), (st.x2, getattr(st.desc, "amax_in2", None))):
             if t is not None and a:
                 check(lib().tsod_amax_reset(a, 1, stream_ptr()), "amax_reset")
                 check(lib().tsod_absmax_f32(ptr(t), t.numel(), a, stream_ptr()), "absmax")
@@ -401,7 +403,7 @@ class Plan:
         flops = 2 * px * (fb.cin * fb.cmid + 9 * fb.cmid * fb.cmid + fb.cmid * fb.cout)
         # what the block must move however it is computed: x in, out out, the weights (the residual is x again: counted once)
         alg = 4 * (px * fb.cin + px * fb.cout + fb.cin * fb.cmid + 9 * fb.cmid * fb.cmid + fb.cmid * fb.cout)
-        st = FusedStep(name, self.steps[-1][0], args, d, flops, alg)
+        st = FusedStep(name, self.steps[-1][0], args, d, flops, alg, x=x)
         self.fused_steps.append(st)
         self.gemm_steps.append(st)
         self.flops += flops
@@ -435,7 +437,14 @@ class Plan:
         call).  A HIP graph captured from the plan replays the pointer it was captured with."""
         st = self.stem_step
         nhwc4 = isinstance(x, _ffi.NHWC4Images)
-        t = x.data if nhwc4 else x.contiguous()
+        t = x.data if nhwc4 else x
+        d = st.desc
+        want = (d.N, d.H, d.W, 4) if nhwc4 else (d.N, 3, d.H, d.W)
+        if t.dtype != torch.float32 or tuple(t.shape) != want or t.device != self.device:
+            raise TsodError(f"the one-launch stem expects float32 {want} on {self.device}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+        t = t.contiguous()                   # (a copy only for a strided view; a batch slice x[i:i+1] is contiguous as it is)
+        if t.data_ptr() % (16 if nhwc4 else 4):
+            t = t.clone()
         st.desc.in_layout = _ffi.STEM_NHWC4 if nhwc4 else _ffi.STEM_NCHW
         st.args[1] = ptr(t)
         self._bound_input = t
@@ -468,6 +477,7 @@ class Plan:
         import math
         stage_input(self, x)
         by_args = {id(st.args): st for st in self.conv_steps}
+        by_args.update({id(st.args): st for st in self.fused_steps if st.x is not None})     # (one-launch bottlenecks: the static path's exponent of x)
         s = stream_ptr()
         seen = {}
         for fn, args in self.steps:
@@ -479,7 +489,7 @@ class Plan:
                 e = fp16x2_activation_exp(m, headroom_bits)
                 e = min(e, self.a_exps.get(st.name, e)) if st.name in seen else e      # (image groups of one layer: the smallest)
                 self.a_exps[st.name] = e
-                if int(st.desc.precision) == _ffi.PREC_FP16X2:
+                if step_precision(st) == _ffi.PREC_FP16X2:
                     st.desc.a_scale_exp = e
                 seen[st.name] = (m, e)
             rc = fn(*args, s)
@@ -512,6 +522,12 @@ class Plan:
         s = stream_ptr()
         for st in self.gemm_steps:
             st.fn(*st.args, s)
+        # the pooled buffers now hold what a pass leaves; inputs that no matrix launch produces (a max pool's or a depthwise conv's
+        # output) may be a LATER tensor of the forward: make every input's range words an upper bound of the bytes that are there
+        # (the producers of the pass add their own abs-max on top), so that no fp16x2 launch is timed on out-of-range operands
+        if self.dynamic_scale:
+            for st in self.gemm_steps:
+                self._refresh_amax_for(st)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -909,31 +925,54 @@ class PlanOwner:
 
     def set_conv_precision(self, precision: str):
         """Arithmetic of the dense conv GEMMs: "f32" (v_mfma_f32_32x32x2_f32), "bf16x3" (three exact bf16 pieces per
-        operand, six bf16 MFMAs per 16 k: f32-accurate, less matrix-pipe time) or "fp16x2" (two fp16 pieces of 16 x per operand,
-        three fp16 MFMAs per 16 k: f32-accurate while |x| < 4094 - raise_if_error() reports a violation).  Existing plans are dropped."""
+        operand, six bf16 MFMAs per 16 k: f32-accurate, less matrix-pipe time) or "fp16x2" (two fp16 pieces of 2^e x per operand,
+        three fp16 MFMAs per 16 k: f32-accurate for every finite input - e follows each tensor's abs-max per forward through its
+        range words; only with the words switched off (TSOD_NO_RANGE_WORDS / dynamic_scale False) is the static 2^4 and its
+        |x| < 4094 range in force; raise_if_error() reports non-finite accumulators either way).  Existing plans are dropped."""
         if precision not in ("f32", "bf16x3", "fp16x2"):
             raise ValueError(precision)
         self.conv_precision = precision
         self.__dict__["_plans"] = OrderedDict()
         return self
 
-    def raise_if_error(self):
-        """Surface what the fp16x2 launches of ANY plan of this owner reported since the last call (evicted plans included:
-        the word belongs to the owner): a launch that ended with non-finite accumulators - non-finite input, or, for a conv
-        without range words, an activation beyond the static exponent's range; its outputs are garbage.  One device read (a sync)."""
-        flag = self.__dict__.get("_range_flag")
-        if flag is None:
-            return
-        if int(flag.item()) != 0:
-            with torch.inference_mode():
-                flag.zero_()
+    RANGE_WORDS = 64             # range words per device: one per in-flight slot (slot % 64)
+
+    def _range_word(self, device, slot: int = 0) -> torch.Tensor:
+        """The int32 word the fp16x2 launches of this owner's plans of (device, slot) report into (include/tsod.h: range_flag): a
+        one-element view of ONE int32[64] tensor per device, which belongs to the owner (it survives plan eviction), so every
+        in-flight slot has a word of its own (serving.result(ticket) blames the request at fault, not whichever is collected
+        first) and a module that holds plans on two devices never hands a launch a pointer into the other device's memory."""
+        words = self.__dict__.setdefault("_range_words", {})
+        device = torch.device(device)
+        t = words.get(device)
+        if t is None:
+            t = words[device] = torch.zeros(self.RANGE_WORDS, dtype=torch.int32, device=device)
+        i = int(slot) % self.RANGE_WORDS
+        return t[i:i + 1]
+
+    def raise_if_error(self, slot=None):
+        """Surface what the fp16x2 launches of ANY plan of this owner (``slot``: of that in-flight slot only) reported since the
+        last call (evicted plans included: the words belong to the owner): a launch that ended with non-finite accumulators -
+        non-finite input, or, for a conv without range words, an activation beyond the static exponent's range; its outputs are
+        garbage.  One 256-byte device read per device (a sync)."""
+        bad = False
+        for t in self.__dict__.get("_range_words", {}).values():
+            v = t if slot is None else t[int(slot) % self.RANGE_WORDS:int(slot) % self.RANGE_WORDS + 1]
+            if bool(v.cpu().any()):
+                bad = True
+                with torch.inference_mode():
+                    v.zero_()
+        if bad:
             raise TsodError("fp16x2: a conv layer ended with non-finite accumulators - non-finite input (or, without range words, "
                             f"an activation beyond +-{65504 // (1 << FP16X2_A_SCALE_EXP)}); its outputs are garbage")
 
-    def range_flag_raised(self) -> bool:
-        """The word as it is now (one 4-byte device read): True once a launch that has COMPLETED reported (serving.result())."""
-        flag = self.__dict__.get("_range_flag")
-        return flag is not None and int(flag.item()) != 0
+    def range_flag_raised(self, slot=None) -> bool:
+        """The words as they are now (one small device read): True once a launch that has COMPLETED reported (serving.result())."""
+        for t in self.__dict__.get("_range_words", {}).values():
+            v = t if slot is None else t[int(slot) % self.RANGE_WORDS:int(slot) % self.RANGE_WORDS + 1]
+            if bool(v.cpu().any()):
+                return True
+        return False
 
     def _init_plan_owner(self):
         self.__dict__["_plans"] = OrderedDict()
@@ -947,6 +986,7 @@ class PlanOwner:
         self.__dict__["_plans"] = OrderedDict()
         self.__dict__["_packed_cache"] = {}
         self.__dict__.setdefault("_a_exps", {}).clear()
+        self.__dict__["_range_words"] = {}       # (per device; the plans that pointed at the old words are gone with them)
         self.__dict__["weights_version"] = self.__dict__.get("weights_version", 0) + 1
 
     def _bump_version(self):
@@ -958,7 +998,7 @@ class PlanOwner:
 
     def __getstate__(self):                       # copy.deepcopy / pickling: plans hold ctypes objects and raw pointers
         st = self.__dict__.copy()
-        st["_plans"], st["_packed_cache"] = OrderedDict(), {}
+        st["_plans"], st["_packed_cache"], st["_range_words"] = OrderedDict(), {}, {}
         return st
 
     def _cached_plan(self, key, build: Callable):
@@ -967,21 +1007,22 @@ class PlanOwner:
         if plan is None:
             plan = plans[key] = build()
             shared = self.__dict__.setdefault("_a_exps", {})      # fp16x2 activation exponents by layer name, for every plan of this owner
-            flag = self.__dict__.get("_range_flag")
-            if flag is None and isinstance(plan, Plan):
-                flag = self.__dict__["_range_flag"] = plan.range_flag      # ONE range word per owner: survives plan eviction, one read
             if isinstance(plan, Plan):
+                # the owner's range word of (the plan's device, its in-flight slot): survives plan eviction
+                slot = key[2] if isinstance(key, tuple) and len(key) > 2 and isinstance(key[2], int) else 0
+                flag = self._range_word(plan.device, slot)
+                assert flag.device == plan.device
                 plan.a_exps = shared
                 plan.range_flag = flag
                 plan.on_calibrated = self._bump_version           # (a graph captured at detector level holds the old exponents)
-            for st in getattr(plan, "conv_steps", ()):
-                st.exps = shared
-                st.range_flag = flag
-                if int(st.desc.precision) == _ffi.PREC_FP16X2:    # (built in that arithmetic: choose() ran before the dict was shared)
-                    st.desc.a_scale_exp = int(shared.get(st.name, FP16X2_A_SCALE_EXP))
+                for st in plan.conv_steps:
+                    st.exps = shared
+                    st.range_flag = flag
+                    if int(st.desc.precision) == _ffi.PREC_FP16X2:    # (built in that arithmetic: choose() ran before the dict was shared)
+                        st.desc.a_scale_exp = int(shared.get(st.name, FP16X2_A_SCALE_EXP))
+                        st.desc.range_flag = ptr(flag)
+                for st in plan.fused_steps:
                     st.desc.range_flag = ptr(flag)
-            for st in getattr(plan, "fused_steps", ()):
-                st.desc.range_flag = ptr(flag)
             while len(plans) > max(1, int(self.max_plans)):
                 plans.popitem(last=False)
         else:

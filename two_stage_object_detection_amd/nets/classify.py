@@ -96,12 +96,18 @@ class HarNetRoIHead(PlanOwner, nn.Module):
                 torch.cuda.current_stream(dev).synchronize()
         return w2
 
-    def _gemm_kw(self, dev, prec, feat_amax, range_flag):
+    def _gemm_kw(self, dev, prec, feat_amax, range_flag, fc7=None):
+        """What the fused GEMM's arithmetic needs beside the f32 weights.  fp16x2 scales its input with range words: the
+        backbone plan's (``feat_amax``) inside the detector forward; for the staged API (``forward`` / ``forward_nhwc`` /
+        ``FasterRCNN.forward(mode="head")`` on a RoI count whose tuned choice is fp16x2) a temporary set filled by one
+        tsod_absmax_f32 pass over the pooled features in front of the GEMM."""
         if prec == _ffi.PREC_BF16X3:
             return {"w3": self._w3(dev)}
         if prec == _ffi.PREC_FP16X2:
             if not feat_amax:
-                raise TsodError("HarNetRoIHead: the fp16x2 arithmetic needs the feature map's range words; pin another arithmetic")
+                if fc7 is None:
+                    raise TsodError("HarNetRoIHead: the fp16x2 arithmetic needs range words for its input")
+                feat_amax = hip_ops.absmax(fc7, hip_ops.new_amax_words(fc7.device))
             w2, e = self._w2(dev)
             # the pooled means are bounded by the feature map's abs-max: its words give a safe scale
             return {"w2": w2, "w_scale_exp": e, "amax_in": feat_amax, "range_flag": range_flag}
@@ -131,7 +137,7 @@ class HarNetRoIHead(PlanOwner, nn.Module):
         M, K = fc7.shape
         tile, split, prec = self.__dict__.get("_gemm_choice", {}).get(M, (0, 0, 0))
         both = hip_ops.conv2d_nhwc(fc7.view(1, 1, M, K), w.view(w.shape[0], 1, 1, K), shift=b, tile=tile, split_k=split,
-                                   precision=prec, **self._gemm_kw(feat.device, prec, feat_amax, range_flag)
+                                   precision=prec, **self._gemm_kw(feat.device, prec, feat_amax, range_flag, fc7)
                                    ).view(M, w.shape[0])                           # [n*R, pad4(5*n_class)]
         # views into the fused output (row pitch 408 for 81 classes): same values and shapes as the reference's two
         # Linear outputs; .contiguous() them if a consumer needs dense storage

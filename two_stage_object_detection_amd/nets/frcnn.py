@@ -77,9 +77,9 @@ class FasterRCNN(nn.Module):
         return t
 
     def _feature_words(self, x, slot):
-        """(range words of the backbone's output for this input geometry / slot or None, the extractor's range word)."""
+        """(range words of the backbone's output for this input geometry / slot or None, the range word of that plan's slot)."""
         plan = self.extractor._plan_for(x, slot)
-        return (getattr(plan, "output_amax", 0) or None), self.extractor.__dict__.get("_range_flag")
+        return (getattr(plan, "output_amax", 0) or None), getattr(plan, "range_flag", None)
 
     def forward(self, x, scale=1., mode="forward", slot=0):
         """``slot`` (added, non-breaking) selects an independent set of backbone buffers, so that forwards issued on
@@ -248,7 +248,7 @@ class FasterRCNN(nn.Module):
         ext.forward_nhwc(example)
         pf = ext._plan_for(example)
         t1 = head_time(pf) if pf.stem_step is not None else float("inf")   # (inf: a backbone whose stem the kernel does not cover)
-        ext.set_fuse_stem(False)                                    # (the caller switches; plans of both structures stay cached)
+        ext.set_fuse_stem(False)                                    # (the caller switches; every switch drops the owner's plans, packed weights stay)
         ext.forward_nhwc(example)
         if verbose:
             print(f"  one-launch stem: {t1 * 1e3:.1f} us against {t3 * 1e3:.1f} us for layout pass + conv1 + max pool -> "

@@ -111,15 +111,19 @@ class RegionProposalNetwork(PlanOwner, nn.Module):
                 torch.as_tensor(self.anchor_base, dtype=torch.float32).to(dev).contiguous(), n_loc, n_sc)
         return ent
 
-    def _conv_kw(self, pc, prec, feat_amax, range_flag):
+    def _conv_kw(self, pc, prec, feat_amax, range_flag, feat=None):
         """Arguments of the fused conv that depend on the arithmetic: the pre-split weight image kept beside the f32 weights
-        (never re-split per call: a constant of a captured graph) and, for fp16x2, the feature map's range words."""
+        (never re-split per call: a constant of a captured graph) and, for fp16x2, the feature map's range words - the
+        backbone plan's (``feat_amax``) inside the detector forward, or, for a feature map somebody else produced (the staged
+        API: ``forward`` / ``forward_nhwc`` / ``FasterRCNN.forward(mode="rpn")`` on a geometry whose tuned choice is fp16x2), a
+        temporary set filled by one tsod_absmax_f32 pass over ``feat`` in front of the GEMM."""
         if prec == _ffi.PREC_BF16X3:
             return {"w3": weights_bf16x3(pc)}
         if prec == _ffi.PREC_FP16X2:
             if not feat_amax:
-                raise TsodError("RegionProposalNetwork: the fp16x2 arithmetic needs the feature map's range words (a backbone plan "
-                                "with dynamic_scale); pin another arithmetic for this GEMM")
+                if feat is None:
+                    raise TsodError("RegionProposalNetwork: the fp16x2 arithmetic needs the feature map's range words")
+                feat_amax = hip_ops.absmax(feat, hip_ops.new_amax_words(feat.device))
             w2, e = weights_fp16x2(pc)
             return {"w2": w2, "w_scale_exp": e, "amax_in": feat_amax, "range_flag": range_flag}
         return {}
@@ -133,7 +137,7 @@ class RegionProposalNetwork(PlanOwner, nn.Module):
         pc, base, n_loc, n_sc = self._pack(feat.device)
         tile, split, prec = self.__dict__.get("_gemm_choice", {}).get((n, h, w), (0, 0, 0))
         fused = hip_ops.conv2d_nhwc(feat, pc.w, shift=pc.shift, tile=tile, split_k=split, precision=prec,
-                                    **self._conv_kw(pc, prec, feat_amax, range_flag)).view(n * h * w, pc.cout)
+                                    **self._conv_kw(pc, prec, feat_amax, range_flag, feat)).view(n * h * w, pc.cout)
         boxes, _, keys, anchor = hip_ops.rpn_decode(fused[:, :n_loc], fused[:, n_loc:n_loc + n_sc], base, n, h, w,
                                                     self.feat_stride, img_size[1], img_size[2],
                                                     self.proposal_layer.min_size * scale, want_anchors=want_anchors)

@@ -87,11 +87,12 @@ class InFlightDetector:
         if self._ticket_of[slot] != ticket:
             raise TsodError(f"InFlightDetector: ticket {ticket} is no longer resident (its slot was reused)")
         self._done[slot].synchronize()
-        # the conv launches' range word (one 4-byte device read: ~10 us of host time per request, nothing on the GPU's critical
-        # path).  A set word means SOME forward that has completed on this detector ran an fp16x2 layer into non-finite
-        # accumulators (non-finite input): this step's outputs may be garbage - never hand them out as valid.
-        if self.model.extractor.range_flag_raised():
-            self.model.extractor.raise_if_error()
+        # the range word of THIS slot's conv launches (one small device read: ~10 us of host time per request, nothing on the
+        # GPU's critical path).  Every slot has its own plan and its own word, so a set word means THIS step ran an fp16x2 layer
+        # into non-finite accumulators (non-finite input): its outputs are garbage - never hand them out as valid - while the
+        # other requests in flight are unaffected and keep their results.
+        if self.model.extractor.range_flag_raised(slot):
+            self.model.extractor.raise_if_error(slot)
         return self._outputs[slot]
 
     def drain(self) -> None:
