@@ -87,7 +87,10 @@ enum { TSOD_TILE_AUTO = 0, TSOD_TILE_128x128 = 1, TSOD_TILE_128x64 = 2, TSOD_TIL
        TSOD_TILE_D192x128 = 23 /* FP16X2 only: 6 waves along M, 16-float stages, 4-stage ring, one workgroup per CU.  A row-tile size
                                   of its own against tile-count cliffs: M = 4200 rows x 1024 channels (layer3's 1x1 expand conv at
                                   batch 1) is 264 tiles of 128 x 128 - one more chip-wave for 8 tiles - and 176 of these */,
-       TSOD_TILE_COUNT = 24 };
+       TSOD_TILE_D64x128_K64 = 24 /* FP16X2 only: 8 waves (2 along M x 4 along K), 64-float stages, 3-stage ring, one workgroup per CU:
+                                     half the row granularity of D128x128_K32 at the same MFMAs per wave and phase - small-M layers
+                                     fill the chip with whole tiles (four K quarters meet in LDS) instead of K-slices that meet in memory */,
+       TSOD_TILE_COUNT = 25 };
 /* arithmetic of the contraction.  F32: v_mfma_f32_32x32x2_f32 (a k-ordered f32 fma chain).  BF16X3: every f32 operand cut
  * exactly into three bf16 pieces (hi + mid + lo == x), six piece products per k accumulated in f32 on
  * v_mfma_f32_32x32x16_bf16: f32-level accuracy (error ~1.3e-7 of sum|a*b|) at 0.375x the matrix-pipe time; storage,

@@ -268,9 +268,12 @@ def rpn_forward(sd, feat, img_size, scale=1.0, feat_stride=16, mode="training",
     (nets/rpn.py:86-88).  Returns (rpn_locs [B,A,4], rpn_scores [B,A,2], rois [B,n_post,4],
     anchor [1,A,4]) -- the 4-tuple of the working code."""
     n, _, h, w = feat.shape
-    locs = F.conv2d(feat, sd[prefix + "loc.weight"], sd[prefix + "loc.bias"])
+    # (float32 feature map: the reference's arithmetic, bit for bit.  A float64 feature map - detector_forward(exact=True) - runs
+    #  the two convs in float64 and rounds their outputs ONCE to float32; everything behind them is the reference's f32 code)
+    wt = lambda k: sd[prefix + k].to(feat.dtype)          # noqa: E731
+    locs = F.conv2d(feat, wt("loc.weight"), wt("loc.bias")).float()
     locs = locs.permute(0, 2, 3, 1).contiguous().view(n, -1, 4)
-    scores = F.conv2d(feat, sd[prefix + "score.weight"], sd[prefix + "score.bias"])
+    scores = F.conv2d(feat, wt("score.weight"), wt("score.bias")).float()
     scores = scores.permute(0, 2, 3, 1).contiguous().view(n, -1, 2)
     fg = F.softmax(scores, dim=-1)[:, :, 1].contiguous().view(n, -1)
     base = generate_basic_anchor(ratios=ratios, anchor_scales=anchor_scales)
@@ -282,7 +285,7 @@ def rpn_forward(sd, feat, img_size, scale=1.0, feat_stride=16, mode="training",
             r, d = r
             dbg.append(d)
         rois.append(r.unsqueeze(0))
-    rois = torch.cat(rois, dim=0).to(feat.dtype)
+    rois = torch.cat(rois, dim=0).float()
     out = (locs, scores, rois, anchor.unsqueeze(0).float())
     if return_debug:
         return out, {"fg": fg, "per_image": dbg}
@@ -303,11 +306,16 @@ def roi_head_forward(sd, feat, rois, roi_indices, img_size, roi_size=7, spatial_
     fm[:, [0, 2]] = flat[:, [0, 2]] / img_size[1] * wf
     fm[:, [1, 3]] = flat[:, [1, 3]] / img_size[0] * hf
     idx = roi_indices.reshape(-1, 1).to(fm.dtype).repeat_interleave(R, dim=0)
+    exact = feat.dtype == torch.float64   # detector_forward(exact=True): pooling picks among the feature values rounded once to f32,
+    feat32 = feat.float()                 # the mean and the two Linear layers run in float64 and are rounded once
     if roi_op == "align":      # the added option (RoIAlign, sampling_ratio 2, aligned=False); the reference's head is "pool"
-        pooled = roi_align(feat, torch.cat([idx, fm], dim=1), (roi_size, roi_size), spatial_scale, 2, False)
+        pooled = roi_align(feat32, torch.cat([idx, fm], dim=1), (roi_size, roi_size), spatial_scale, 2, False)
     else:
-        pooled = roi_pool(feat, torch.cat([idx, fm], dim=1), (roi_size, roi_size), spatial_scale)
+        pooled = roi_pool(feat32, torch.cat([idx, fm], dim=1), (roi_size, roi_size), spatial_scale)
+    if exact:
+        pooled = pooled.double()
     fc7 = F.adaptive_avg_pool2d(pooled, (1, 1)).flatten(1)
-    cls_locs = F.linear(fc7, sd[prefix + "cls_loc.weight"], sd[prefix + "cls_loc.bias"])
-    scores = F.linear(fc7, sd[prefix + "score.weight"], sd[prefix + "score.bias"])
+    wt = lambda k: sd[prefix + k].to(fc7.dtype)           # noqa: E731
+    cls_locs = F.linear(fc7, wt("cls_loc.weight"), wt("cls_loc.bias")).float()
+    scores = F.linear(fc7, wt("score.weight"), wt("score.bias")).float()
     return cls_locs.view(n, -1, cls_locs.shape[1]), scores.view(n, -1, scores.shape[1])

@@ -30,10 +30,21 @@ def extractor_forward(sd, x, backbone="resnet50", prefix="extractor."):
 
 @torch.inference_mode()
 def detector_forward(sd, x, backbone="resnet50", scale=1.0, mode="training",
-                     ratios=(0.5, 1, 2), anchor_scales=(8, 16, 32), return_debug=False, roi_op="pool"):
+                     ratios=(0.5, 1, 2), anchor_scales=(8, 16, 32), return_debug=False, roi_op="pool", exact=False):
     """FasterRCNN.forward(x, scale, mode="forward") (nets/frcnn.py:30-40) ->
-    (roi_cls_locs [B,R,4*n_class], roi_scores [B,R,n_class], rois [B,R,4], roi_indices [B])."""
+    (roi_cls_locs [B,R,4*n_class], roi_scores [B,R,n_class], rois [B,R,4], roi_indices [B]).
+
+    ``exact=False`` (default): the reference's arithmetic - torch CPU float32 throughout - bit for bit.
+    ``exact=True``: the SAME network evaluated in float64 wherever the reference sums (trunk, RPN convs, the head's mean and two
+    Linear layers), every tensor that enters the reference's f32 box code (RPN loc / score, the feature map RoI pooling picks
+    from, the head's outputs) rounded ONCE to float32; decode, clamp, sort, NMS, padding and pooling are the reference's own
+    float32 operations.  That is the exact value of the reference's math up to one rounding: what a float32 pipeline - the
+    reference's own CPU run included - can be measured AGAINST (scripts/config4_truth.py: on HarDNet-68 at 3x800x1333 the
+    reference's f32 path is 11-12 RoI ulps from it, as far as any of the HIP arithmetics)."""
     stride, _ = BACKBONES[backbone]
+    if exact:
+        sd = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in sd.items()}
+        x = x.double()
     feat = extractor_forward(sd, x, backbone)
     rpn = rpn_forward(sd, feat, tuple(x.shape[1:]), scale=scale, feat_stride=stride, mode=mode,
                       ratios=ratios, anchor_scales=anchor_scales, prefix="rpn.", return_debug=return_debug)

@@ -494,20 +494,22 @@ def test_detector_with_the_one_launch_stem(dev, r50):
         model.extractor.drop_plan(slot=1)
 
 
-def _check_images(got, sd, x, backbone, images, max_pos, roi_atol=1e-3):
+def _check_images(got, sd, x, backbone, images, max_pos, roi_atol=1e-3, exact=False):
     """Rows of the batched outputs ``got`` for ``images`` against single-image oracle forwards; returns the worst figures.
-    ``roi_atol`` > 1e-3 (config 4 only, see there): rows pair up at that distance, scores / offsets / classes keep the 1e-3 bar,
-    and ``rows_beyond_1e-3`` counts the rows that have no partner at the bar itself."""
+    ``exact``: the reference is the oracle's float64 evaluation of the network (oracle.detector_forward(exact=True): the exact value
+    of the reference's math, rounded once) instead of its float32 run.  ``roi_atol`` > 1e-3 (config 4 against the FLOAT32 oracle
+    only, see there): rows pair up at that distance, scores / offsets / classes keep the 1e-3 bar, and ``rows_beyond_1e-3`` counts
+    the rows that have no partner at the bar itself."""
     from two_stage_object_detection_amd.testing import compare_detector_outputs
     worst = {"rows_positional_mismatch": 0, "rows_unmatched": 0, "class_mismatch": 0, "max_abs_roi": 0.0, "max_abs_score": 0.0,
              "max_abs_cls_loc": 0.0, "rows_beyond_1e-3": 0}
     for i in images:
         with torch.inference_mode():
-            ref = oracle.detector_forward(sd, x[i:i + 1], backbone=backbone)
+            ref = oracle.detector_forward(sd, x[i:i + 1], backbone=backbone, exact=exact)
         row = [got[0][i:i + 1], got[1][i:i + 1], got[2][i:i + 1], got[3][:1]]
         r = compare_detector_outputs(row, ref, atol=roi_atol)
         r["rows_beyond_1e-3"] = r["rows_unmatched"] if roi_atol == 1e-3 else compare_detector_outputs(row, ref)["rows_unmatched"]
-        print("image", i, json.dumps(r))
+        print("image", i, "against the float64 evaluation" if exact else "against the float32 oracle", json.dumps(r))
         assert r["roi_indices_equal"] and r["rows_unmatched"] == 0 and r["class_mismatch"] == 0 and r["max_abs_roi"] <= roi_atol, (i, r)
         assert r["max_abs_score"] <= 1e-3 and r["max_abs_cls_loc"] <= 1e-3 and r["rows_positional_mismatch"] <= max_pos, (i, r)
         for k in worst:
@@ -547,19 +549,23 @@ def test_config3_batch16_in_the_form_bench_times(dev):
 def test_config4_hardnet68_batch8_in_the_form_bench_times(dev):
     """... and BASELINE config 4 (HarDNet-68, batch 8): `bench.py --backbone hardnet68 --batch 8` runs ~60 of the 67 dense layers
     in fp16x2 after tuning, every one taking its scale from range words that SEVERAL producers share (a HarDBlock's buffer:
-    block input + every layer's depthwise output).  Two images against the oracle.
+    block input + every layer's depthwise output).  Two images of the batch.
 
-    The margin, as it is.  This detector's proposals reach ~900 px and its RoI coordinates are f32 values whose spacing there is
-    6.1e-5: the 1e-3 bar is 16 of those.  Two f32 pipelines over 67 dense + 67 depthwise layers differ by up to 15 of them in
-    the all-f32 plan (9.2e-4: test_config4_hardnet68_batch8_full_size, which holds the bar) and by up to 17 (1.04e-3) in the
-    tuned plan on 3 of 600 rows; the summation order of the last GEMM in front of exp(dw) * w does not move it
-    (scripts/config4_margin.py: f32 whole, 4 / 8 / 16 K-slices, bf16x3 - same rows, same distance).  So this test pairs rows
-    at 1.25e-3 (20 spacings), keeps scores / offsets at 1e-3 and classes exact, and REPORTS how many rows sit beyond the bar
-    (at most 4 of 600 accepted); ResNet-50 - the headline - sits at 2.4e-4 and keeps the bar everywhere."""
+    The bar, and against what.  This detector's proposals reach ~900 px; RoI coordinates there are f32 values 6.1e-5 apart, so
+    1e-3 is 16.4 of them.  scripts/config4_truth.py (round 5) evaluated the reference's network in float64 and measured every
+    float32 pipeline against it: the reference's own CPU f32 run sits 11.5-12 spacings from the exact RoIs, the HIP f32 plan
+    11-14, bf16x3 12, fp16x2 11-12.5, the tuned mix 11-12 (feature maps: 1.35-1.76e-6 rms of the abs-max for ALL of them, the
+    fp16x2 / bf16x3 / tuned plans a little below the two f32 chains) - and any two of them 13-17 spacings from EACH OTHER, whatever
+    the arithmetic: the sum of two independent distances to the truth.  So "within 1e-3 of the reference's f32 run" is a coin
+    flip for ANY correct f32-accurate pipeline over these 134 layers (it is what round 4's 1.04-1.08e-3 on 1-3 of 600 rows was),
+    and no choice of arithmetic by the tuner can change that (FasterRCNN.tune(parity_budget=...) exists and ends at the f32
+    plan for any budget below that distance).  What CAN be held, and is held here STRICTLY - 1e-3, no row beyond it - is the
+    distance of the benched form to the exact result: the float64 evaluation of the reference's network
+    (oracle.detector_forward(exact=True)).  Against the reference's f32 run the test keeps scores / offsets at 1e-3, classes
+    exact, pairs rows at 1.25e-3 (the two pipelines' distances to the truth added up) and reports the rows beyond 1e-3.
+    ResNet-50 - the headline - keeps 1e-3 against the f32 run everywhere (2.4e-4)."""
     from two_stage_object_detection_amd.testing import synthetic_detector
-    model, sd = synthetic_detector("hardnet68", num_classes=80, seed=0)
-    oracle.calibrate_bn(sd, _img((2, 3, 256, 320), seed=99), oracle.hardnet_trunk, arch=68, prefix="extractor.")
-    model.load_state_dict(sd)
+    model, sd = synthetic_detector("hardnet68", num_classes=80, seed=0, conditioned=True)    # (the weights bench.py times)
     model = model.to(dev).eval()
     x = _img((8, 3, 800, 1333), seed=21)
     xg = x.to(dev)
@@ -571,10 +577,62 @@ def test_config4_hardnet68_batch8_in_the_form_bench_times(dev):
         torch.cuda.synchronize()
         model.raise_if_error()
         got = [o.cpu() for o in outs[:4]]
+        exact = _check_images(got, sd, x, "hardnet68", (0, 5), max_pos=12, roi_atol=1e-3, exact=True)
         worst = _check_images(got, sd, x, "hardnet68", (0, 5), max_pos=12, roi_atol=1.25e-3)
-    print("config 4 as benched: fp16x2 layers", n_h2, "of", len(table["serial"]), worst, "margin to 1e-3:", 1e-3 - worst["max_abs_roi"])
-    assert worst["rows_beyond_1e-3"] <= 2, worst                                   # (per image; 2 + 1 measured)
+    print("config 4 as benched: fp16x2 layers", n_h2, "of", len(table["serial"]), "against the float64 evaluation:", exact,
+          "margin to 1e-3:", 1e-3 - exact["max_abs_roi"], "| against the float32 oracle:", worst)
+    assert exact["rows_beyond_1e-3"] == 0 and exact["rows_unmatched"] == 0 and exact["max_abs_roi"] <= 1e-3, exact
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
-        json.dump({"fp16x2_layers": n_h2, **worst}, open(os.path.join(out_dir, "config4_benched_form_parity.json"), "w"))
+        json.dump({"fp16x2_layers": n_h2, "against_float64_evaluation": exact, "against_float32_oracle": worst},
+                  open(os.path.join(out_dir, "config4_benched_form_parity.json"), "w"))
     assert n_h2 >= 30, table["serial"]
+
+
+def test_tune_with_a_parity_budget_demotes_layers_until_it_holds(dev):
+    """FasterRCNN.tune(parity_budget=...): GPU against GPU (the all-f32 plan on the tuning input), layers leave their tuned
+    arithmetic for the f32 MFMA kernel in the order of what they buy until the decoded RPN boxes are within the budget; the
+    demotions are in the table and travel with it.  A budget of zero ends at the f32 plan itself (bit-identical outputs); a
+    budget above what the tuned plan measures demotes nothing."""
+    from two_stage_object_detection_amd.testing import compare_detector_outputs, synthetic_detector
+    model, sd = synthetic_detector("resnet50", num_classes=20, seed=0)
+    model = model.to(dev).eval()
+    x = _img((1, 3, 320, 448), seed=3)
+    xg = x.to(dev)
+    kw = dict(precisions=(0, 2), schedules=("serial",), in_sequence=0, reps=1, fuse_bottleneck=False, fuse_stem=False, splits=[1, -1])
+    with torch.inference_mode():
+        ref = oracle.detector_forward(sd, x, backbone="resnet50")
+        loose = model.tune(xg, parity_budget=1.0, **kw)
+        pb = loose["parity_budget"]
+        assert pb["held"] and pb["demoted"] == [] and 0.0 < pb["before_px"] == pb["after_px"] <= 1.0, pb
+        n_h2 = sum(1 for r in loose["serial"] if r[3] == 2)
+        assert n_h2 >= 20
+        # the same table under half the distance it measured (the budget step alone: re-tuning would draw another table)
+        import copy
+        tight = copy.deepcopy(loose)
+        model.import_tuning(tight, xg)
+        pt = tight["parity_budget"] = model._hold_parity_budget(xg, tight, ["serial"], 0.5 * pb["before_px"])
+        print("parity budget", pt)
+        assert pt["held"] and 1 <= len(pt["demoted"]) and pt["after_px"] <= pt["budget_px"] < pt["before_px"], pt
+        assert abs(pt["before_px"] - pb["before_px"]) <= 1e-6
+        for name in pt["demoted"]:
+            if not name.startswith("rpn"):
+                assert [r for r in tight["serial"] if r[0] == name][0][3] == 0, name
+        out = [o.cpu() for o in model(xg)]
+        model.raise_if_error()
+        assert compare_detector_outputs(out, ref)["ok"]
+        zero = model.tune(xg, parity_budget=0.0, **kw)
+        pz = zero["parity_budget"]
+        assert pz["held"] and pz["after_px"] == 0.0 and all(r[3] == 0 for r in zero["serial"]), pz
+        out0 = [o.clone() for o in model(xg)]
+        # the same model under the cost model's all-f32 plan: the very same launches
+        model.extractor.set_structure(None)
+        model.import_tuning({"serial": [[r[0], 0, 0, 0] for r in zero["serial"]], "heads": zero["heads"]}, xg)
+        outf = model(xg)
+        for a, b in zip(out0, outf):
+            assert torch.equal(a, b)
+        # a second detector pins the tight table through import_tuning: the demotions travel
+        m2, _ = synthetic_detector("resnet50", num_classes=20, seed=0)
+        m2 = m2.to(dev).eval()
+        m2.import_tuning(tight, xg)
+        assert m2.extractor._plan_for(xg).export_tiles() == [tuple(r) for r in tight["serial"]]

@@ -109,3 +109,44 @@ def test_trainer_checkpoint_to_hip_forward_with_packed_cache(dev, tmp_path, back
     assert os.path.basename(p).startswith(f"tiles-{backbone}-2x256x320-")
     assert weight_cache.load_tiles(m1, str(cache), x.shape, dev) == plan.export_tiles()
     assert weight_cache.load_tiles(m1, str(cache), (1, 3, 64, 64), dev) is None
+
+
+def test_tuned_table_is_cached_on_disk_and_a_second_start_does_not_tune(dev, tmp_path):
+    """FasterRCNN.tune(cache_dir=...): the first call tunes and writes the table (keyed by weights + config, device name, input
+    geometry, the tuning arguments and the library's sha256), a second detector with the same weights pins it in well under two
+    seconds and runs the same kernels (bit-identical outputs); other arguments or other weights miss."""
+    import time
+    from two_stage_object_detection_amd import weight_cache
+    from two_stage_object_detection_amd.testing import synthetic_detector
+    x = _img((1, 3, 224, 288), seed=7).to(dev)
+    kw = dict(precisions=(0, 2), in_flight=2, reps=1, in_sequence=0, in_flight_refine=0, splits=[1, -1])
+    m1, _ = synthetic_detector("resnet50", num_classes=20, seed=0)
+    m1 = m1.to(dev).eval()
+    with torch.inference_mode():
+        t0 = time.perf_counter()
+        table = m1.tune(x, cache_dir=str(tmp_path), **kw)
+        t_tune = time.perf_counter() - t0
+        assert "cached" not in table and len(list(tmp_path.glob("tuning-resnet50-1x224x288-*.json"))) == 1
+        out1 = [o.clone() for o in m1(x)]
+        m2, _ = synthetic_detector("resnet50", num_classes=20, seed=0)
+        m2 = m2.to(dev).eval()
+        m2(x)                                                          # (plan building and weight packing are not what is measured)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hit = m2.tune(x, cache_dir=str(tmp_path), **kw)
+        t_hit = time.perf_counter() - t0
+        assert hit.get("cached") is True and t_hit < 2.0 and t_hit < t_tune, (t_hit, t_tune)
+        assert [list(r) for r in hit["serial"]] == [list(r) for r in table["serial"]] and hit["heads"] == table["heads"]
+        assert hit["fuse_stem"] == table["fuse_stem"] and hit["fuse_bottleneck"] == table["fuse_bottleneck"]
+        assert m2.extractor._plan_for(x).export_tiles() == m1.extractor._plan_for(x).export_tiles()
+        out2 = m2(x)
+        for a, b in zip(out1, out2):
+            assert torch.equal(a, b)
+        m2.raise_if_error()
+        # another argument set, other weights: a miss each (a new file)
+        m2.tune(x, cache_dir=str(tmp_path), **dict(kw, splits=[1]))
+        assert len(list(tmp_path.glob("tuning-*.json"))) == 2
+        m3, _ = synthetic_detector("resnet50", num_classes=20, seed=1)
+        m3 = m3.to(dev).eval()
+        args = {"precisions": [0, 2]}
+        assert weight_cache.tuning_path(str(tmp_path), m3, x.shape, dev, args) != weight_cache.tuning_path(str(tmp_path), m1, x.shape, dev, args)

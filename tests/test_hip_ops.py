@@ -896,7 +896,7 @@ def test_conv_fp16x2_scale_follows_the_tensor(ops, dev, scale):
     x2n = ops.nchw_to_nhwc(x2.to(dev))
     words2 = ops.absmax(x2n, ops.new_amax_words(dev, 1))
     wst = torch.cat([w1.flatten(1), wd.flatten(1)], dim=1).contiguous().to(dev)
-    for tile in (22, 14):
+    for tile in (22, 14, 24):
         out = ops.conv2d_nhwc(xn, wst, segs=[(0, Cin)], tile=tile, split_k=1, precision=2, x2=x2n, amax_in=words, amax_in2=words2, range_flag=flag)
         assert (ops.nhwc_to_nchw(out).cpu() - ref2).abs().max().item() <= 3e-6 * math.sqrt(Cin + C2) * scale * 1000.0 + 1e-5 * scale, tile
     assert int(flag.item()) == 0
@@ -1046,7 +1046,7 @@ def test_conv_fp16x2_lds_dma_over_channel_segments(ops, dev, N, H, W, segs, Cout
     words = ops.absmax(xn, ops.new_amax_words(dev, 1))
     tol = (3e-6 * math.sqrt(K) + 1e-5) * max(1.0, float(ref.abs().max()) / 4.0)
     kw = dict(segs=segs, scale=scale.to(dev), shift=shift.to(dev), residual=rn, act=1, slope=0.25, precision=2)
-    for tile in (17, 19, 21, 22, 23):
+    for tile in (17, 19, 21, 22, 23, 24):
         for split in (1, 2, -1):
             out = ops.conv2d_nhwc(xn, wp, tile=tile, split_k=split, amax_in=words, **kw)
             err = (ops.nhwc_to_nchw(out).cpu() - ref).abs().max().item()

@@ -258,14 +258,14 @@ def test_head_choices_roundtrip_as_json():
 
 
 def test_fp16x2_host_side_choices():
-    """The host side of the fp16x2 arithmetic: which tiles have it (every bf16x3 tile but the two 64-row LDS-DMA shapes, plus d192x128), the
+    """The host side of the fp16x2 arithmetic: which tiles have it (every bf16x3 tile but the two 64-row LDS-DMA shapes, plus d192x128 and d64x128k64), the
     activation exponent picked for a measured range (16x headroom under fp16's 65504, clamped), and the weight exponent
     (max |w| just below 2^14)."""
     import torch
     from two_stage_object_detection_amd import _ffi
     from two_stage_object_detection_amd.engine import FP16X2_A_SCALE_EXP, fp16x2_activation_exp
     from two_stage_object_detection_amd.hip_ops import fp16x2_weight_scale_exp
-    assert set(_ffi.FP16X2_TILE_IDS) == (set(_ffi.BF16X3_TILE_IDS) - {18, 20}) | {23} and 22 in _ffi.FP16X2_TILE_IDS   # (d192x128: fp16x2 only)
+    assert set(_ffi.FP16X2_TILE_IDS) == (set(_ffi.BF16X3_TILE_IDS) - {18, 20}) | {23, 24} and 22 in _ffi.FP16X2_TILE_IDS   # (d192x128, d64x128k64: fp16x2 only)
     assert _ffi.PREC_NAMES[_ffi.PREC_FP16X2] == "fp16x2" and FP16X2_A_SCALE_EXP == 4
     for m in (1e-3, 0.7, 100.0, 4093.0, 3e4, 1e9):
         e = fp16x2_activation_exp(m)
@@ -403,3 +403,87 @@ def test_stem_weight_fragment_layout():
                     kw, ci = kw0 + (i >> 2), i & 3
                     ref = 0.0 if kw == 7 or ci == 3 else float(w[32 * cb + pi(j), ci, kh, kw]) * 2.0 ** e
                     assert abs(float(hi[i] + lo[i]) - ref) <= abs(ref) * 2.0 ** -21
+
+
+def test_precomputed_bn_statistics_of_the_synthetic_hardnets_are_what_the_oracle_computes():
+    """bench.py builds its HarDNet model with BatchNorm statistics loaded from a committed file (no oracle on the path that
+    builds the timed model); the file must hold exactly what the tests' own conditioning (oracle.calibrate_bn on two seeded
+    images) computes for these weights, and a file made for other weights must be refused."""
+    import numpy as np
+    import oracle
+    import pytest
+    import torch
+    from two_stage_object_detection_amd import testing
+    model, sd = testing.synthetic_detector("hardnet39", num_classes=20, seed=0, conditioned=True)
+    _, ref = testing.synthetic_detector("hardnet39", num_classes=20, seed=0)
+    x = torch.rand((2, 3, 256, 320), generator=torch.Generator().manual_seed(99))
+    oracle.calibrate_bn(ref, x, oracle.hardnet_trunk, arch=39, prefix="extractor.")
+    assert set(sd) == set(ref)
+    for k in sd:
+        assert torch.allclose(sd[k], ref[k], rtol=1e-5, atol=1e-7), k
+    live = model.state_dict()
+    for k in sd:
+        assert torch.equal(live[k], sd[k]), k
+    for bb in ("hardnet68", "hardnet85"):
+        data = np.load(testing.synthetic_bn_path(bb, 0))
+        assert "__weights_checksum__" in data.files and len(data.files) > 100
+    with pytest.raises(RuntimeError):
+        testing.synthetic_detector("hardnet39", num_classes=20, seed=1, conditioned=True)      # no file for that seed
+    # resnet: nothing to condition (its BN is identity by construction of the reference's init)
+    _, a = testing.synthetic_detector("resnet50", num_classes=20, seed=0, conditioned=True)
+    _, b = testing.synthetic_detector("resnet50", num_classes=20, seed=0)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_tuned_table_cache_key_and_round_trip(tmp_path, monkeypatch):
+    """weight_cache.save_tuning / load_tuning on the CPU: the key moves with the arguments, the geometry, the weights and the
+    library's hash; a damaged file is a miss, not an error."""
+    import torch
+    from two_stage_object_detection_amd import testing, weight_cache
+    model, _ = testing.synthetic_detector("resnet50", num_classes=20, seed=0)
+    table = {"serial": [["conv1", 3, 1, 2]], "heads": {"rpn": {}, "head": {}}, "fuse_stem": False, "fuse_bottleneck": False}
+    args = {"precisions": [0, 2], "in_flight": 2}
+    shape = (1, 3, 224, 288)
+    p = weight_cache.save_tuning(model, str(tmp_path), shape, "cpu", args, table)
+    assert weight_cache.load_tuning(model, str(tmp_path), shape, "cpu", args) == table
+    assert weight_cache.load_tuning(model, str(tmp_path), shape, "cpu", dict(args, in_flight=4)) is None
+    assert weight_cache.load_tuning(model, str(tmp_path), (1, 3, 256, 288), "cpu", args) is None
+    keep = model.rpn.loc.bias.detach().clone()
+    with torch.no_grad():
+        model.rpn.loc.bias.add_(1.0)
+    assert weight_cache.load_tuning(model, str(tmp_path), shape, "cpu", args) is None            # other weights
+    with torch.no_grad():
+        model.rpn.loc.bias.copy_(keep)
+    assert weight_cache.load_tuning(model, str(tmp_path), shape, "cpu", args) == table
+    monkeypatch.setattr(weight_cache, "library_hash", lambda: "another-build")
+    assert weight_cache.load_tuning(model, str(tmp_path), shape, "cpu", args) is None            # another libtsod.so
+    monkeypatch.undo()
+    open(p, "w").write("{not json")
+    assert weight_cache.load_tuning(model, str(tmp_path), shape, "cpu", args) is None
+    assert len(weight_cache.library_hash()) == 16
+
+
+def test_bench_parity_rule_with_two_references():
+    """bench.parity_of: ok = within 1e-3 of the oracle's float32 run, or within 1e-3 of its float64 evaluation AND within 1.25e-3 of
+    the float32 run with equal classes; beyond both is not ok."""
+    import torch
+    import bench
+    R, C = 4, 3
+    rois = torch.tensor([[[10., 20., 110., 220.], [300., 40., 900., 700.], [5., 5., 50., 60.], [400., 300., 800., 600.]]])
+    scores = torch.tensor([[[0.1, 2.0, 0.3], [1.5, 0.2, 0.1], [0.0, 0.1, 3.0], [0.3, 0.2, 0.9]]])
+    locs = torch.zeros(1, R, 4 * C)
+    idx = torch.zeros(1, dtype=torch.int32)
+    ref = (locs, scores, rois, idx)
+    exact = (locs, scores, rois + 7e-4, idx)                  # the f32 run itself is 7e-4 from the exact value
+    same = {"serial": [locs, scores, rois.clone(), idx]}
+    p = bench.parity_of(same, ref, exact)
+    assert p["ok"] and p["within_atol"] and p["exact"]["within_atol"] and p["max_abs_roi"] == 0.0
+    far_from_f32 = {"serial": [locs, scores, rois + 1.15e-3, idx]}   # 1.15e-3 from the f32 run, 4.5e-4 from the exact value
+    p = bench.parity_of(far_from_f32, ref, exact)
+    assert not p["within_atol"] and p["exact"]["within_atol"] and p["ok"] and p["float32_run_at_1.25e-3"]["rows_unmatched"] == 0
+    assert bench.parity_of(far_from_f32, ref)["ok"] is False   # without the exact evaluation: the float32 rule alone
+    wrong = {"serial": [locs, scores, rois + 3e-3, idx]}
+    assert bench.parity_of(wrong, ref, exact)["ok"] is False
+    flipped = scores.clone()
+    flipped[0, 3] = torch.tensor([0.95, 0.2, 0.9])            # another arg-max class: never ok
+    assert bench.parity_of({"serial": [locs, flipped, rois + 1.15e-3, idx]}, ref, exact)["ok"] is False

@@ -21,13 +21,13 @@ ACT_NONE, ACT_PRELU, ACT_RELU6, ACT_RELU = 0, 1, 2, 3
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4
 TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "64x128", 5: "128x128w8", 6: "128x64w8", 7: "256x128w8",
               8: "64x64s1", 9: "128x64w8s1", 10: "64x64s1k64", 11: "128x64w8s1k64", 12: "64x64w1s1", 13: "128x64w2s1", 14: "128x64s1", 15: "64x128s1", 16: "128x128s1",
-              17: "d128x128", 18: "d64x128", 19: "d256x128", 20: "d64x128s2", 21: "d128x256", 22: "d128x128k32", 23: "d192x128"}
+              17: "d128x128", 18: "d64x128", 19: "d256x128", 20: "d64x128s2", 21: "d128x256", 22: "d128x128k32", 23: "d192x128", 24: "d64x128k64"}
 TILE_IDS = tuple(range(1, 17))
 PREC_F32, PREC_BF16X3, PREC_FP16X2 = 0, 1, 2
 PREC_NAMES = {0: "f32", 1: "bf16x3", 2: "fp16x2"}
-DMA_TILE_IDS = (17, 18, 19, 20, 21, 22, 23)                         # through LDS-DMA (23: fp16x2 only): one channel segment, Cin % 16 / % 32 == 0, bf16x3 ONLY
-BF16X3_TILE_IDS = (3, 8, 9, 10, 14, 15, 16) + tuple(t for t in DMA_TILE_IDS if t != 23)   # tiles that exist as bf16x3 variants (include/tsod.h)
-FP16X2_TILE_IDS = tuple(t for t in BF16X3_TILE_IDS if t not in (18, 20)) + (23,)   # fp16x2: every bf16x3 tile but the 64-row LDS-DMA ones, + d192x128
+DMA_TILE_IDS = (17, 18, 19, 20, 21, 22, 23, 24)                         # through LDS-DMA (23: fp16x2 only): one channel segment, Cin % 16 / % 32 == 0, bf16x3 ONLY
+BF16X3_TILE_IDS = (3, 8, 9, 10, 14, 15, 16) + tuple(t for t in DMA_TILE_IDS if t not in (23, 24))   # tiles that exist as bf16x3 variants (include/tsod.h)
+FP16X2_TILE_IDS = tuple(t for t in BF16X3_TILE_IDS if t not in (18, 20)) + (23, 24)   # fp16x2: every bf16x3 tile but the 64-row LDS-DMA ones, + d192x128
 
 
 class TsodError(RuntimeError):

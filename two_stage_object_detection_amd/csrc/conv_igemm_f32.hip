@@ -1185,7 +1185,7 @@ conv_dma_kernel(const ConvParams p) {
     constexpr int PA_W = A_PIECES / WAVES, PB_W = (B_PIECES + WAVES - 1) / WAVES, P = PA_W + PB_W;
     constexpr bool B_PAD = B_PIECES % WAVES != 0;
     constexpr int PATCHES = WAVES * 32 * kPatchLD * 4;
-    static_assert(S * STAGE >= PATCHES && S * STAGE >= WAVES * 2 * 16 * 64 * 4, "epilogue patches / K-half exchange fit the ring");
+    static_assert(S * STAGE >= PATCHES && S * STAGE >= WAVES * (WAVES_K == 4 ? 4 : 2) * 16 * 64 * 4, "epilogue patches / K-half exchange fit the ring");
     // Per-stage operands of the K loop come from a TABLE in LDS, built once per K range: entry j (16 bytes) describes K-step
     // kt_begin + j = {byte offset its filter tap and channel run add to a pixel's base address, byte offset of its k-groups in a
     // row of the weight image, the tap's bit in the rows' validity masks, flags}.  The K loop is bound by the instructions its
@@ -1340,15 +1340,17 @@ conv_dma_kernel(const ConvParams p) {
 #ifdef TSOD_DIAG_NODMA
     const int nodma_steps = __builtin_amdgcn_readfirstlane(*(volatile int *)&g_nodma_steps);
 #endif
+    // (channel blocks of the block-major order: 32 channels, or a whole stage where a stage is longer than that)
+    constexpr int CBLK = BK > 32 ? BK : 32;
     int u_kt = kt_begin, u_kh, u_kw, u_ci, u_cb;
     {
-        constexpr int SUB = 32 / BK;
+        constexpr int SUB = CBLK / BK;
         const int blk = kt_begin / SUB, sub = kt_begin - blk * SUB, taps = p.KH * p.KW;
         const int cb = blk / taps, tap_c = blk - cb * taps;      // channel-block-major
         const int kb = kt_begin * BK, tap_t = kb / p.Cin;        // tap-major
         const int tap = p.cmajor ? tap_c : tap_t;
-        u_cb = p.cmajor ? cb * 32 : 0;
-        u_ci = p.cmajor ? cb * 32 + sub * BK : kb - tap_t * p.Cin;
+        u_cb = p.cmajor ? cb * CBLK : 0;
+        u_ci = p.cmajor ? cb * CBLK + sub * BK : kb - tap_t * p.Cin;
         u_kh = tap / p.KW;
         u_kw = tap - u_kh * p.KW;
     }
@@ -1385,7 +1387,7 @@ conv_dma_kernel(const ConvParams p) {
         const bool tap_done = ci1 - u_cb >= p.ci_wrap;
         const bool row_done = tap_done & (kw1 == p.KW);
         const bool all_taps = row_done & (kh1 == p.KH);
-        u_cb = all_taps ? u_cb + 32 : u_cb;
+        u_cb = all_taps ? u_cb + CBLK : u_cb;
         u_ci = tap_done ? u_cb : ci1;
         u_kw = tap_done ? (row_done ? 0 : kw1) : u_kw;
         u_kh = row_done ? (all_taps ? 0 : kh1) : u_kh;
@@ -1487,7 +1489,7 @@ conv_dma_kernel(const ConvParams p) {
         // split behind MFMAs 4..11, one pair of elements per two MFMAs; this wave's DMA pieces one per pair.
 #define TSOD_DMA2(I) do { if constexpr ((I) < P) issue_piece(std::integral_constant<int, (I)>{}, std::integral_constant<bool, TABLE>{}, slot_off); } while (0)
 #define TSOD_MF2(n) acc[0][(n) & 3], cur.a[PA[(n) >> 2]], cur.b[(n) & 3][PB[(n) >> 2]]
-        static_assert(NPL != 2 || P <= 5, "DMA slots of an fp16x2 phase");
+        static_assert(NPL != 2 || P <= 6, "DMA slots of an fp16x2 phase");
         if constexpr (TABLE) {
             lds_read16<0>(t_e, tab_ptr);
             tab_ptr += 16;
@@ -1533,6 +1535,7 @@ conv_dma_kernel(const ConvParams p) {
         TSOD_SPLIT2(6, raw0.z, raw0.w, 1)
         TSOD_SPLIT2(8, raw1.x, raw1.y, 2)
         TSOD_SPLIT2(10, raw1.z, raw1.w, 3)
+        TSOD_DMA2(5);                                            // (the 64-row tile with four K quarters: six pieces per wave and stage)
 #undef TSOD_SPLIT2
 #undef TSOD_MF2
 #undef TSOD_DMA2
@@ -1638,7 +1641,7 @@ conv_dma_kernel(const ConvParams p) {
         // the stage table of this K range (entries 0 .. nk + S: the loop issues stages S .. nk - 1 + S, one more when nk is odd;
         // built while the prologue's DMAs are in flight, visible to every wave behind the barrier that ends the prologue)
         if constexpr (TABLE) {
-            constexpr int SUB = 32 / BK;
+            constexpr int SUB = CBLK / BK;
             const int taps = p.KH * p.KW;
             for (int j = tid; j <= nk + S; j += THREADS) {
 #if defined(TSOD_DIAG_NOADVANCE)
@@ -1660,7 +1663,7 @@ conv_dma_kernel(const ConvParams p) {
                         if (p.cmajor) {
                             const int blk = step / SUB, cb = blk / taps;
                             tap = blk - cb * taps;
-                            ci = cb * 32 + (step - blk * SUB) * BK;
+                            ci = cb * CBLK + (step - blk * SUB) * BK;
                         } else {
                             tap = step * BK / p.Cin;
                             ci = step * BK - tap * p.Cin;
@@ -1817,6 +1820,27 @@ conv_dma_kernel(const ConvParams p) {
         }
         __syncthreads();
         conv_epilogue<BM, BN, 32, 64, THREADS, BALANCED ? 3 : 4>(pe, acc2, smem, tid, wm, wk, m0, n0, sm);
+    } else if constexpr (WAVES_K == 4) {
+        // the four K quarters of a 32 x 128 stripe sit in waves (wm, 0 .. 3): every wave puts its four 32 x 32 blocks into LDS
+        // ([wave][block][e][lane], lane-contiguous) and wave (wm, wk) finishes block wk = columns [32 wk, 32 wk + 32) as the sum of the
+        // four quarters IN K ORDER (quarter 0 first, whoever adds: bit-reproducible).  The own quarter goes through LDS too - picking it
+        // from the registers would index the accumulators by a run-time wave number.
+        f32x16 acc1[1][1];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) smem[((wave * 4 + b) * 16 + e) * 64 + lane] = acc[0][b][e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float v = smem[(((wm + WAVES_M * 0) * 4 + wk) * 16 + e) * 64 + lane];
+            v += smem[(((wm + WAVES_M * 1) * 4 + wk) * 16 + e) * 64 + lane];
+            v += smem[(((wm + WAVES_M * 2) * 4 + wk) * 16 + e) * 64 + lane];
+            v += smem[(((wm + WAVES_M * 3) * 4 + wk) * 16 + e) * 64 + lane];
+            acc1[0][0][e] = v;
+        }
+        __syncthreads();
+        conv_epilogue<BM, BN, 32, 32, THREADS, BALANCED ? 3 : 4>(pe, acc1, smem, tid, wm, wk, m0, n0, sm);
     } else {
         conv_epilogue<BM, BN, 32, 128, THREADS, BALANCED ? 3 : 4>(pe, acc, smem, tid, wm, wn, m0, n0, sm);
     }
@@ -1910,14 +1934,14 @@ const TileInfo kTiles[TSOD_TILE_COUNT] = {
     {128, 128, 256, 2, 1.02f, 32, 1, 1},
     {128, 128, 256, 2, 0.80f, 16, 4, 1, 1}, {64, 128, 256, 1, 0.95f, 32, 3, 1, 1}, {256, 128, 512, 1, 0.72f, 16, 4, 1, 1},
     {64, 128, 256, 2, 0.98f, 32, 2, 1, 1}, {128, 256, 512, 1, 0.74f, 16, 4, 1, 1}, {128, 128, 512, 1, 0.70f, 32, 3, 1, 1},
-    {192, 128, 384, 1, 0.74f, 16, 4, 1, 1}};
+    {192, 128, 384, 1, 0.74f, 16, 4, 1, 1}, {64, 128, 512, 1, 0.80f, 64, 3, 1, 1}};
 // bf16x3 = 1: the tile also exists as a bf16x3 variant (three bf16 planes per operand fit the 64 KB of static LDS)
 
 // workgroups per CU: the f32 figure (VGPR / LDS bound), for bf16x3 additionally capped by its larger LDS footprint
 // tiles that exist in the fp16x2 arithmetic: the register-staged bf16x3 tiles and d128x128k32
 bool fp16x2_tile(int t) {   // (the 64-row LDS-DMA tiles would need six DMA slots in a 12-MFMA phase: not built)
     return t == TSOD_TILE_D128x128_K32 || t == TSOD_TILE_D128x128 || t == TSOD_TILE_D256x128 || t == TSOD_TILE_D128x256 || t == TSOD_TILE_D192x128 ||
-           (kTiles[t].bf16x3 && !kTiles[t].dma);
+           t == TSOD_TILE_D64x128_K64 || (kTiles[t].bf16x3 && !kTiles[t].dma);
 }
 
 int residency(int tile, int prec) {
@@ -1947,7 +1971,7 @@ int validate(const tsod_conv2d_desc *d) {
     TSOD_REQUIRE(d->tile >= 0 && d->tile < TSOD_TILE_COUNT && d->split_k >= -2 && d->split_k <= 64, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->precision == TSOD_PREC_BF16X3 || d->precision == TSOD_PREC_FP16X2, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->precision == TSOD_PREC_F32 || d->tile == TSOD_TILE_AUTO || kTiles[d->tile].bf16x3, TSOD_ERR_UNSUPPORTED);
-    TSOD_REQUIRE(d->tile != TSOD_TILE_D192x128 || d->precision == TSOD_PREC_FP16X2, TSOD_ERR_UNSUPPORTED);   // (fp16x2 only)
+    TSOD_REQUIRE((d->tile != TSOD_TILE_D192x128 && d->tile != TSOD_TILE_D64x128_K64) || d->precision == TSOD_PREC_FP16X2, TSOD_ERR_UNSUPPORTED);   // (fp16x2 only)
     TSOD_REQUIRE(d->precision != TSOD_PREC_F32 || d->tile == TSOD_TILE_AUTO || !kTiles[d->tile].dma, TSOD_ERR_UNSUPPORTED);
     if (d->precision == TSOD_PREC_FP16X2) {                       // (the register-staged bf16x3 tiles and the 128x128 / 32-k LDS-DMA tile)
         TSOD_REQUIRE(d->tile == TSOD_TILE_AUTO || fp16x2_tile(d->tile), TSOD_ERR_UNSUPPORTED);
@@ -2136,7 +2160,7 @@ Sched resolve(const tsod_conv2d_desc *d) {
         if (d->tile != TSOD_TILE_AUTO && d->tile != t) continue;
         if (d->precision && !kTiles[t].bf16x3) continue;
         if (!d->precision && kTiles[t].dma) continue;
-        if (t == TSOD_TILE_D192x128 && d->precision != TSOD_PREC_FP16X2) continue;
+        if ((t == TSOD_TILE_D192x128 || t == TSOD_TILE_D64x128_K64) && d->precision != TSOD_PREC_FP16X2) continue;
         if (d->precision == TSOD_PREC_FP16X2 && !fp16x2_tile(t)) continue;
         if (!tile_ok_for(d, t)) continue;        // (also an explicitly named tile: the caller gets TSOD_ERR_UNSUPPORTED)
         if (d->split_k != 0) {
@@ -2269,8 +2293,9 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
     p.tiles_m = sc.tiles_m; p.tiles_n = sc.tiles_n;
     p.dp_tiles = sc.dp_tiles; p.split = sc.split; p.ksteps_per_split = sc.ksteps_per_split; p.sk_q = sc.sk_q;
     p.nmajor = sc.nmajor;
-    p.cmajor = (kTiles[sc.tile].dma && d->KH * d->KW > 1 && p.Cin % 32 == 0 && kstep_order_override() != 0) ? 1 : 0;
-    p.ci_wrap = p.cmajor ? 32 : p.Cin;
+    const int cblk = kTiles[sc.tile].bk > 32 ? kTiles[sc.tile].bk : 32;      // channel block of the block-major K-step order (conv_dma_kernel: CBLK)
+    p.cmajor = (kTiles[sc.tile].dma && d->KH * d->KW > 1 && p.Cin % cblk == 0 && kstep_order_override() != 0) ? 1 : 0;
+    p.ci_wrap = p.cmajor ? cblk : p.Cin;
     if (sc.rem_tiles > 0)
         TSOD_REQUIRE(workspace != nullptr && workspace_bytes >= sc.ws_bytes && tsod_aligned16(workspace), TSOD_ERR_WORKSPACE);
     p.tickets = static_cast<int *>(workspace);
@@ -2303,6 +2328,7 @@ extern "C" int tsod_conv2d_dual_f32(const tsod_conv2d_desc *d, const float *in, 
             case TSOD_TILE_D256x128: launch_dma_tile<256, 16, 1, 4, 1, 2>(p, sc.grid, s); break;
             case TSOD_TILE_D128x256: launch_dma_tile<128, 16, 1, 4, 2, 2>(p, sc.grid, s); break;
             case TSOD_TILE_D192x128: launch_dma_tile<192, 16, 1, 4, 1, 2>(p, sc.grid, s); break;
+            case TSOD_TILE_D64x128_K64: launch_dma_tile<64, 64, 4, 3, 1, 2>(p, sc.grid, s); break;
             default: launch_tile<64, 64, 32, 32, 2, 2, 32, 2>(p, sc.grid, s); break;      // TSOD_TILE_64x64 (two LDS stages)
         }
         return tsod_launch_status();

@@ -120,7 +120,8 @@ class FasterRCNN(nn.Module):
             return rpn_choice, self.head.autotune(fc7, feat_amax, flag)
 
     def tune(self, example, precisions=(0, 1, 2), in_flight=1, schedules=("serial", "in_flight"), splits=None, in_sequence=None,
-             in_flight_refine=None, reps=3, heads=True, fuse_bottleneck="auto", fuse_stem="auto", verbose=False):
+             in_flight_refine=None, reps=3, heads=True, fuse_bottleneck="auto", fuse_stem="auto", verbose=False, cache_dir=None,
+             parity_budget=None):
         """Autotune every GEMM of the forward for ``example``'s geometry ([B,3,H,W] on the GPU) and pin the result: per conv
         layer the fastest (tile, K-slice schedule, arithmetic) among ``precisions`` (0 f32 MFMA, 1 bf16x3, 2 fp16x2 - all three
         f32-accurate; the fp16x2 scale follows every tensor per forward through its range words, so no calibration pass and no
@@ -138,7 +139,21 @@ class FasterRCNN(nn.Module):
         Returns the tables as plain JSON-able data {"serial": [...], "in_flight": [...], "heads": {...}, "fuse_bottleneck": bool,
         "fuse_stem": bool}
         - feed it back through ``import_tuning`` (another process, another rank) or ``InFlightDetector(tiles=...)``.  Afterwards
-        the plan of slot 0 runs the serial table when that was tuned, else the in-flight one."""
+        the plan of slot 0 runs the serial table when that was tuned, else the in-flight one.
+        ``cache_dir``: keep the table on disk (weight_cache.save_tuning), keyed by the weights + config hash, the device name, the
+        input geometry, these arguments and the sha256 of libtsod.so: a later call with the same key - another process start of the
+        same server - pins the stored table in about a second instead of tuning for 25-60 s (the returned table then carries
+        "cached": True).  A table is a speed choice for one device and one library build; anything else misses.
+        ``parity_budget`` (pixels; default None = off): after the timing passes, hold the tuned plan to the ALL-f32 plan of the
+        same model on ``example`` (GPU against GPU - no oracle on the product path): the figure is the largest distance between
+        the two plans' decoded RPN boxes (every anchor that passes the min-size filter in both; the continuous quantity in front
+        of the sort / NMS decisions).  While it exceeds the budget, layers leave their tuned arithmetic for the f32 MFMA kernel,
+        the layer whose demotion moves the figure most first (``_hold_parity_budget``); the demotions, the figure before and
+        after and the budget are recorded under "parity_budget" and travel with the table (import_tuning, the N > 1 broadcast).
+        What to expect of it (scripts/config4_truth.py): two f32-accurate pipelines over a deep net differ
+        by the SUM of their distances to the exact result, whatever their arithmetic - on HarDNet-68 at 3x800x1333 every
+        pipeline (f32, bf16x3, fp16x2, the tuned mix AND the reference's own CPU f32 path) sits 11-14 RoI ulps from a float64
+        evaluation and 13-17 from each other - so a budget below that distance demotes every layer and ends at the f32 plan."""
         from ..engine import refine_in_flight
         require_cuda(example, "FasterRCNN.tune")
         B = example.shape[0]
@@ -149,6 +164,22 @@ class FasterRCNN(nn.Module):
         want = [k for k in ("serial", "in_flight") if k in schedules and (k == "serial" or in_flight > 1)]
         if not want:
             raise TsodError("FasterRCNN.tune: nothing to tune (schedules / in_flight)")
+        cache_args = None
+        if cache_dir is not None:
+            from .. import weight_cache
+            cache_args = {"precisions": [int(v) for v in precisions], "in_flight": int(in_flight), "schedules": want,
+                          "parity_budget": None if parity_budget is None else float(parity_budget),
+                          "splits": None if splits is None else [int(v) for v in splits], "in_sequence": int(in_sequence),
+                          "in_flight_refine": int(in_flight_refine), "reps": int(reps), "heads": bool(heads),
+                          "fuse_bottleneck": str(fuse_bottleneck), "fuse_stem": str(fuse_stem)}
+            hit = weight_cache.load_tuning(self, cache_dir, example.shape, example.device, cache_args)
+            if hit is not None:
+                try:
+                    self.import_tuning(hit, example, schedule=want[0] if "serial" not in want else "serial")
+                    hit["cached"] = True
+                    return hit
+                except TsodError:
+                    pass                     # (a table this build refuses: tune again and overwrite it)
         ext = self.extractor
         table = {}
 
@@ -219,7 +250,95 @@ class FasterRCNN(nn.Module):
             if heads:
                 self.autotune_heads(example)
                 table["heads"] = self.head_choices()
+        if parity_budget is not None:
+            with torch.inference_mode():
+                table["parity_budget"] = self._hold_parity_budget(example, table, want, float(parity_budget), verbose)
+        if cache_args is not None:
+            weight_cache.save_tuning(self, cache_dir, example.shape, example.device, cache_args, table)
         return table
+
+    def _rpn_boxes(self, x, slot=0):
+        """(decoded + clamped RPN boxes [B,A,4], keys [B,A] (-inf: filtered)) of one forward of the backbone + fused RPN conv: the
+        continuous quantity the proposal layer's discrete decisions are taken on."""
+        with hip_ops.ARENA.scope((self._uid, slot)):
+            feat = self.extractor.forward_nhwc(x, slot)
+            feat_amax, flag = self._feature_words(x, slot)
+            fused, _, _ = self.rpn.propose(feat, tuple(x.shape[1:]), 1., feat_amax=feat_amax, range_flag=flag)
+            n, h, w, _ = feat.shape
+            _, base, n_loc, n_sc = self.rpn._pack(feat.device)
+            boxes, _, keys, _ = hip_ops.rpn_decode(fused[:, :n_loc], fused[:, n_loc:n_loc + n_sc], base, n, h, w, self.feat_stride,
+                                                   x.shape[2], x.shape[3], self.rpn.proposal_layer.min_size * 1.)
+        return boxes.clone(), keys.clone()
+
+    def _hold_parity_budget(self, example, table, schedules, budget, verbose=False):
+        """``tune(parity_budget=...)``: demote layers of the tuned table(s) to the f32 MFMA kernel until the tuned plan's decoded
+        RPN boxes are within ``budget`` pixels of the all-f32 plan's on ``example``.  One sweep prices every non-f32 layer (the
+        figure with that layer alone demoted), then layers are demoted in the order of what they buy, re-measuring after each,
+        until the budget holds.  The fused RPN conv is the last "layer" of the list.  One-launch stem / bottlenecks exist in
+        fp16x2 only and stay (both plans run them)."""
+        ext = self.extractor
+        plan = ext._plan_for(example)
+        key = (example.shape[0],) + tuple(ext.forward_nhwc(example).shape[1:3])
+        rpn_choice = self.rpn.__dict__.setdefault("_gemm_choice", {})
+        tuned_rpn = rpn_choice.get(key, (0, 0, 0))
+        sched = "serial" if "serial" in schedules else schedules[0]
+        tuned = [tuple(r) for r in table[sched]]
+        f32_rows = [(r[0], 0, 0, 0) for r in tuned]
+
+        def figure():
+            b, k = self._rpn_boxes(example)
+            ok = torch.isfinite(k) & torch.isfinite(ref_k)
+            d = (b - ref_b).abs().amax(-1)
+            return float(torch.where(ok, d, torch.zeros_like(d)).max())
+        plan.import_tiles(f32_rows)
+        rpn_choice[key] = (0, 0, 0)
+        ref_b, ref_k = self._rpn_boxes(example)
+        rows, rpn_now = list(tuned), tuned_rpn
+
+        def apply():
+            plan.import_tiles(rows)
+            rpn_choice[key] = rpn_now
+        apply()
+        d0 = d = figure()
+        demoted = []
+        if d > budget:
+            cands = [i for i, r in enumerate(rows) if int(r[3]) != 0] + ([-1] if int(tuned_rpn[2]) != 0 else [])
+            price = []
+            for i in cands:                                         # the figure with layer i alone on the f32 kernel
+                keep = rpn_now if i < 0 else rows[i]
+                if i < 0:
+                    rpn_now = (0, 0, 0)
+                else:
+                    rows[i] = f32_rows[i]
+                apply()
+                price.append((figure(), i))
+                if i < 0:
+                    rpn_now = keep
+                else:
+                    rows[i] = keep
+            price.sort()
+            for _, i in price:
+                if d <= budget:
+                    break
+                if i < 0:
+                    rpn_now = (0, 0, 0)
+                else:
+                    rows[i] = f32_rows[i]
+                apply()
+                d = figure()
+                demoted.append("rpn (fused loc + score conv)" if i < 0 else rows[i][0])
+                if verbose:
+                    print(f"  parity budget {budget:g}: {demoted[-1]} -> f32, figure {d:.3g}")
+        apply()
+        gone = set(demoted)
+        for s_ in schedules:                                        # the same layers leave their arithmetic in every schedule's table
+            table[s_] = [[r[0], 0, 0, 0] if r[0] in gone else list(r) for r in table[s_]]
+        if int(rpn_now[2]) == 0 and "heads" in table:
+            table["heads"] = self.head_choices()
+        plan.import_tiles(table[sched])
+        self.extractor.raise_if_error()
+        return {"budget_px": budget, "figure": "max |decoded RPN box - the all-f32 plan's| over the anchors both plans keep, on the tuning input",
+                "before_px": d0, "after_px": d, "demoted": demoted, "layers": len(rows), "held": bool(d <= budget)}
 
     def _stem_pays(self, example, plan, verbose=False, reps=20) -> bool:
         """HIP-event time of the stem alone, back to back: the three launches of ``plan`` (layout pass + its tuned conv1 + max

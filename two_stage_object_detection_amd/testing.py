@@ -7,8 +7,18 @@ from __future__ import annotations
 import torch
 
 
+def synthetic_bn_path(backbone, seed):
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", f"synthetic_bn_{backbone}_seed{seed}.npz")
+
+
+def weights_checksum(sd) -> float:
+    """sum of |w| over the extractor's conv weights (f64): ties a file of pre-computed BN statistics to the weights it was made for"""
+    return float(sum(v.double().abs().sum() for k, v in sd.items() if k.startswith("extractor.") and k.endswith("weight") and v.dim() == 4))
+
+
 def synthetic_detector(backbone="resnet50", num_classes=80, seed=0, mode="training", rpn_loc_gain=None,
-                       rpn_score_gain=None, head_gain=None):
+                       rpn_score_gain=None, head_gain=None, conditioned=False):
     """The detector with seeded random-init weights of the reference architecture:
     ``torch.manual_seed(seed)`` then modules constructed in reference order (ResNet: Kaiming fan_out on
     every conv, BN identity, PReLU 0.25; HarDNet / RPN / head: PyTorch defaults).
@@ -17,6 +27,10 @@ def synthetic_detector(backbone="resnet50", num_classes=80, seed=0, mode="traini
     the RPN softmax and exp() of the box decode; the RPN / head weights are therefore scaled by fixed
     gains so that fg probabilities and box offsets are in the range a trained detector produces
     (loc std ~0.3, logit std ~2).  Gains are constants (no data pass), so weights depend on the seed only.
+    ``conditioned`` (HarDNet only): load the BatchNorm running statistics pre-computed for these very weights
+    (configs/synthetic_bn_<backbone>_seed<seed>.npz, made by scripts/make_synthetic_bn_stats.py: the batch statistics of two
+    seeded images flowing through the trunk).  With identity BN a random-init HarDNet collapses every image to a spatially
+    constant feature map (~2950 of 3000 RPN scores tie exactly): no workload to time or to check a detector on.
     Returns (model on CPU in eval mode, CPU state_dict with the reference's key names)."""
     from .nets.frcnn import FasterRCNN
     torch.manual_seed(seed)
@@ -34,6 +48,22 @@ def synthetic_detector(backbone="resnet50", num_classes=80, seed=0, mode="traini
             lin.weight.mul_(gh)
             lin.bias.mul_(gh)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    if conditioned and backbone.startswith("hardnet"):
+        import numpy as np
+        path = synthetic_bn_path(backbone, seed)
+        try:
+            data = np.load(path)
+        except OSError as e:
+            raise RuntimeError(f"no pre-computed BatchNorm statistics for {backbone} seed {seed} ({path}): run "
+                               "scripts/make_synthetic_bn_stats.py") from e
+        want, have = float(data["__weights_checksum__"]), weights_checksum(sd)
+        if abs(want - have) > 1e-6 * abs(want):
+            raise RuntimeError(f"{path} was made for other weights (checksum {want} vs {have}): re-run scripts/make_synthetic_bn_stats.py")
+        for k in data.files:
+            if k != "__weights_checksum__":
+                sd[k] = torch.from_numpy(data[k]).clone()
+        model.load_state_dict(sd)
+        model.eval()
     return model, sd
 
 

@@ -7,7 +7,11 @@ kept on disk:
 
     <dir>/<backbone>-<sha256 of state_dict + config, 32 hex>.tsodpack torch.save of {"format", "backbone", "hash",
                                                                      "entries": {owner: {layer key: packed state}}}
-    <dir>/tiles-<backbone>-<N>x<H>x<W>-<device name>.json             autotuned (tile, split_k) table per input geometry
+    <dir>/tiles-<backbone>-<N>x<H>x<W>-<device name>.json             a bare (tile, split_k) list per input geometry (save_tiles)
+    <dir>/tuning-<backbone>-<N>x<H>x<W>-<key, 32 hex>.json            what FasterRCNN.tune returned (tables of both schedules, head
+                                                                     GEMM choices, launch structure, demotions) - keyed by the
+                                                                     weights + config hash above, the device name, the input
+                                                                     geometry, the tuning arguments and the sha256 of libtsod.so
 
 The packed state of a layer is plain data (tensors, numbers, strings, lists): the file loads with ``weights_only=True``.
 Everything in it is keyed by ONE hash over what the packed form depends on: the state_dict (keys, dtypes, shapes, bytes - so
@@ -188,3 +192,52 @@ def load_tiles(model, directory, shape, device):
         return None
     with open(path) as f:
         return [tuple(t) for t in json.load(f)]
+
+
+# ----------------------------------------------------------------------------- the tuned table (FasterRCNN.tune(cache_dir=...))
+_LIB_HASH = {}
+
+
+def library_hash() -> str:
+    """sha256 of the libtsod.so this process loaded (16 hex): a table names tile ids and was timed on that library's kernels"""
+    from . import _ffi
+    path = _ffi.LIB_PATH
+    if path not in _LIB_HASH:
+        h = hashlib.sha256()
+        with open(path, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 20), b""):
+                h.update(blk)
+        _LIB_HASH[path] = h.hexdigest()[:16]
+    return _LIB_HASH[path]
+
+
+def tuning_path(directory, model, shape, device, args: dict) -> str:
+    """``args``: the JSON-able tuning arguments the table depends on (FasterRCNN.tune passes its own)."""
+    name = torch.cuda.get_device_name(device) if torch.cuda.is_available() else "cpu"
+    n, _, h, w = (int(v) for v in shape)
+    wh = hashlib.sha256(state_dict_hash(model.state_dict()).encode() + config_fingerprint(model)).hexdigest()[:32]
+    key = hashlib.sha256(json.dumps({"weights": wh, "device": name, "shape": [n, h, w], "lib": library_hash(), "args": args},
+                                    sort_keys=True).encode()).hexdigest()[:32]
+    return os.path.join(directory, f"tuning-{model.backbone}-{n}x{h}x{w}-{key}.json")
+
+
+def save_tuning(model, directory, shape, device, args: dict, table: dict) -> str:
+    os.makedirs(directory, exist_ok=True)
+    path = tuning_path(directory, model, shape, device, args)
+    tmp = path + f".tmp{os.getpid()}"
+    with open(tmp, "w") as f:
+        json.dump(table, f)
+    os.replace(tmp, path)                                   # atomic: ranks tuning concurrently write the same key
+    return path
+
+
+def load_tuning(model, directory, shape, device, args: dict):
+    path = tuning_path(directory, model, shape, device, args)
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return table if isinstance(table, dict) and ("serial" in table or "in_flight" in table) else None
