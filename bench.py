@@ -460,9 +460,13 @@ def rehearse_cpu(args, rank, world):
     # the start-up protocol of the real run: rank 0 "tunes" (here: fabricates a table only it knows), every rank gets it
     t0 = time.perf_counter()
     mine = {"serial": [["conv1", 14, -1, 1], ["layer1.0.conv1", 8, 1, 1]], "heads": {"rpn": {"8x25x42": [3, 1, 1]}, "head": {"2400": [8, 2, 1]}},
+            "fuse_stem": True, "fuse_bottleneck": False,
+            "parity_budget": {"budget_px": 5e-4, "before_px": 9e-4, "after_px": 4e-4, "demoted": ["layer3.0.conv1"], "held": True},
             "tuned_by_rank": 0} if rank == 0 else {"tuned_by_rank": rank}
     tiles = broadcast_json(mine, rank, world)
-    tiles_ok = tiles.get("tuned_by_rank") == 0 and tiles["serial"][0] == ["conv1", 14, -1, 1] and tiles["heads"]["head"]["2400"] == [8, 2, 1]
+    tiles_ok = (tiles.get("tuned_by_rank") == 0 and tiles["serial"][0] == ["conv1", 14, -1, 1] and tiles["heads"]["head"]["2400"] == [8, 2, 1]
+                and tiles.get("fuse_stem") is True and tiles.get("fuse_bottleneck") is False        # the launch structure ...
+                and tiles.get("parity_budget", {}).get("demoted") == ["layer3.0.conv1"])            # ... and the demotions travel with the table
     flags = [None] * world
     if world > 1:
         dist.all_gather_object(flags, bool(tiles_ok))
