@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TSOD_VERSION 241 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
+#define TSOD_VERSION 242 /* 0.2.0: conv descriptor grew (precision, second source), in-launch K-slice combine (zeroed
                             ticket area in the workspace), pitched tsod_detections_f32, new entry points;
                             0.2.1: conv tiles fed by LDS-DMA (bf16x3), balanced K schedule (split_k = -2);
                             0.2.2: tsod_allgather_f32 + communicator helpers (RCCL bound at run time);
@@ -231,11 +231,20 @@ typedef struct tsod_bottleneck_desc {
     float slope;                  /* the block's one PReLU slope */
     int32_t w_exp[3];             /* exponents the three convs' weights were scaled with in wstream */
     int32_t a_scale_exp;          /* static exponent for x when amax_in == NULL */
+    int32_t projection;           /* 0: identity shortcut (Cout == Cin).  1 (version 242): the block's 1x1 projection shortcut at stride 1
+                                   * (models/resnet.py:114-116, layer1's first block) as part of ONE stacked-K GEMM:
+                                   *   out = PReLU([y2 | x] . [W3 s3 | Wd sd]^T + (b3 + bd)),   Cin -> 64 -> 64 -> Cout, Cin % 64 == 0
+                                   * wstream then carries 2 + Cin / 32 steps per 64 output channels of "conv3" (k = the 64 channels of
+                                   * y2, then the Cin channels of x; both BatchNorm scales folded into the weights, ONE exponent
+                                   * w_exp[2] for the stacked matrix: tsod_bottleneck_proj_wstream_bytes), bn's s3 is all ones and its
+                                   * b3 the two shifts added up; the x chunks of a tile's own pixels are read a second time from L2
+                                   * straight into MFMA fragments, there is no residual pass.  (The field sits in what was padding.) */
     int32_t *range_flag;          /* optional, as in tsod_conv2d_desc */
     const uint32_t *amax_in;      /* optional range words of x */
     uint32_t *amax_out;           /* optional range words of out */
 } tsod_bottleneck_desc;
 size_t tsod_bottleneck_wstream_bytes(int32_t Cin, int32_t Cout);
+size_t tsod_bottleneck_proj_wstream_bytes(int32_t Cin, int32_t Cout);    /* desc.projection == 1 */
 int tsod_bottleneck_fp16x2(const tsod_bottleneck_desc *d, const float *x, const void *wstream, const float *bn, float *out,
                            tsod_stream_t stream);
 

@@ -25,7 +25,7 @@ buf = torch.zeros(8 * 8192, dtype=torch.int64, device=dev)
 SHAPES = [(50, 84, 256, 256, 3, "layer3.conv2"), (25, 42, 512, 512, 3, "layer4.conv2"), (100, 167, 128, 128, 3, "layer2.conv2"),
           (50, 84, 1024, 256, 1, "layer3.conv1"), (50, 84, 256, 1024, 1, "layer3.conv3"), (25, 42, 2048, 512, 1, "layer4.conv1"),
           (200, 334, 64, 64, 3, "layer1.conv2")]
-SCHEDS = [(17, 1), (18, 1), (18, 3), (20, 1), (22, 1), (22, 3), (22, -1), (22, -2), (19, -1)]
+SCHEDS = [(17, 1), (18, 1), (18, 3), (20, 1), (22, 1), (22, 3), (22, -1), (22, -2), (19, -1), (24, 1), (24, -1), (24, 2), (24, -2)]
 PREC = int(os.environ.get("TSOD_TIMELINE_PREC", "1"))          # 1 = bf16x3, 2 = fp16x2 (tile d128x128k32 only)
 if len(sys.argv) > 2:
     SHAPES = [s for s in SHAPES if s[5] in sys.argv[2].split(",")]

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_symbols():
         assert hasattr(raw, name), name
     lib = _ffi.lib()
-    assert lib.tsod_version() == 241
+    assert lib.tsod_version() == 242
     assert lib.tsod_status_str(0) == b"ok"
     assert b"workspace" in lib.tsod_status_str(-4)
 
@@ -59,14 +59,14 @@ def test_fused_launch_desc_layouts_match_header(tmp_path):
     import subprocess
     src = tmp_path / "layout2.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tsod.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", '
-                   'sizeof(tsod_bottleneck_desc), offsetof(tsod_bottleneck_desc, w_exp), offsetof(tsod_bottleneck_desc, range_flag), '
+                   'sizeof(tsod_bottleneck_desc), offsetof(tsod_bottleneck_desc, w_exp), offsetof(tsod_bottleneck_desc, projection) * 1000 + offsetof(tsod_bottleneck_desc, range_flag), '
                    'offsetof(tsod_bottleneck_desc, amax_out), sizeof(tsod_stem_desc), offsetof(tsod_stem_desc, slope), '
                    'offsetof(tsod_stem_desc, range_flag), offsetof(tsod_stem_desc, amax_out)); return 0; }\n')
     exe = tmp_path / "layout2"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = tuple(int(v) for v in subprocess.check_output([str(exe)]).split())
     B, S = _ffi.BottleneckDesc, _ffi.StemDesc
-    assert got == (ctypes.sizeof(B), B.w_exp.offset, B.range_flag.offset, B.amax_out.offset,
+    assert got == (ctypes.sizeof(B), B.w_exp.offset, B.projection.offset * 1000 + B.range_flag.offset, B.amax_out.offset,
                    ctypes.sizeof(S), S.slope.offset, S.range_flag.offset, S.amax_out.offset)
     assert (_ffi.STEM_NCHW, _ffi.STEM_NHWC4) == (0, 1)
 

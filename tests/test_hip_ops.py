@@ -919,6 +919,51 @@ def _bottleneck_reference(x, w1, w2, w3, bn, slope):
     return act(F.conv2d(y, w3.double()) * s3 + b3 + x.double()).float()
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,gain,xgain", [(1, 10, 16, 64, 256, 1.0, 1.0), (2, 23, 37, 64, 256, 1.0, 1.0), (1, 31, 20, 128, 192, 1.0, 1.0),
+                                                        (1, 12, 50, 64, 256, 500.0, 1.0), (1, 9, 9, 64, 128, 1e-4, 1.0), (1, 17, 21, 64, 256, 1.0, 300.0)])
+def test_bottleneck_fused_with_projection_shortcut_matches_the_f64_block(ops, dev, N, H, W, Cin, Cout, gain, xgain):
+    """tsod_bottleneck_fp16x2, desc.projection = 1 (layer1's first block, models/resnet.py:114-116): conv3 and the 1x1 projection
+    shortcut as one stacked-K GEMM inside the one-launch bottleneck - y2 chunks from LDS, x chunks from L2, the accumulators
+    changing scale between them - against the f64 CPU block; tile edges, inputs 500x larger / 10^4 x smaller, a shortcut operand
+    300x larger than the main path's (the scale switch), Cin != 64, and the abs-max left for the consumer."""
+    g = torch.Generator().manual_seed(321 + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    x = torch.maximum(x, 0.25 * x) * gain
+    w1 = torch.randn(64, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    w2 = torch.randn(64, 64, 3, 3, generator=g) / math.sqrt(576)
+    w3 = torch.randn(Cout, 64, 1, 1, generator=g) / 8.0
+    wd = torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin) * xgain
+    bn = [torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1 * gain, torch.rand(64, generator=g) + 0.5,
+          torch.randn(64, generator=g) * 0.1 * gain, torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1 * gain]
+    sd_, bd_ = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1 * gain
+    slope = 0.25
+    act = lambda t: torch.where(t >= 0, t, slope * t)      # noqa: E731
+    v4 = lambda v: v.double().view(1, -1, 1, 1)             # noqa: E731
+    y = act(F.conv2d(x.double(), w1.double()) * v4(bn[0]) + v4(bn[1]))
+    y = act(F.conv2d(y, w2.double(), padding=1) * v4(bn[2]) + v4(bn[3]))
+    ref = act(F.conv2d(y, w3.double()) * v4(bn[4]) + v4(bn[5]) + F.conv2d(x.double(), wd.double()) * v4(sd_) + v4(bd_)).float()
+    xn = ops.nchw_to_nhwc(x.to(dev))
+    w2p = ops.pack_conv_weight(w2.to(dev))
+    stacked = torch.cat([w3.double().flatten(1) * bn[4].double().view(-1, 1), wd.double().flatten(1) * sd_.double().view(-1, 1)], dim=1).float()
+    stream, exps = ops.pack_bottleneck_wstream(w1.view(64, Cin).to(dev), w2p, stacked.to(dev), projection=True)
+    bnv = torch.cat(bn[:4] + [torch.ones(Cout), (bn[5].double() + bd_.double()).float()]).to(dev)
+    words = ops.absmax(xn, ops.new_amax_words(dev, 1))
+    wout = ops.new_amax_words(dev, 1)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    out = ops.bottleneck_fused(xn, stream, exps, bnv, Cout, slope, amax_in=words, amax_out=wout, range_flag=flag, cin=Cin)
+    got = ops.nhwc_to_nchw(out).cpu()
+    tol = (3e-6 * math.sqrt(576) + 1e-5) * float(ref.abs().max()) / 4.0 + 1e-6 * gain
+    err = (got - ref).abs().max().item()
+    assert err <= tol, (err, tol)
+    assert int(flag.item()) == 0
+    assert ops.amax_value(wout) == float(out.abs().max())
+    # a non-finite pixel must be reported (PReLU's max / min would turn the NaN into a plausible number)
+    xb = xn.clone()
+    xb[0, H // 2, W // 2, 3] = float("nan")
+    ops.bottleneck_fused(xb, stream, exps, bnv, Cout, slope, amax_in=ops.absmax(xb, ops.new_amax_words(dev, 1)), range_flag=flag, cin=Cin)
+    assert int(flag.item()) == 1
+
+
 @pytest.mark.parametrize("N,H,W,C,gain", [(1, 10, 16, 256, 1.0), (2, 23, 37, 256, 1.0), (1, 31, 20, 64, 1.0), (1, 12, 50, 256, 500.0), (1, 9, 9, 128, 1e-4)])
 def test_bottleneck_fused_matches_the_f64_block(ops, dev, N, H, W, C, gain):
     """tsod_bottleneck_fp16x2: a whole identity bottleneck in one launch (both 64-channel intermediates in LDS) against the f64

@@ -55,7 +55,7 @@ class BottleneckDesc(Structure):
     _fields_ = [
         ("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("in_pitch", c_int32), ("Cmid", c_int32),
         ("Cout", c_int32), ("out_pitch", c_int32), ("slope", c_float), ("w_exp", c_int32 * 3), ("a_scale_exp", c_int32),
-        ("range_flag", c_void_p), ("amax_in", c_void_p), ("amax_out", c_void_p),
+        ("projection", c_int32), ("range_flag", c_void_p), ("amax_in", c_void_p), ("amax_out", c_void_p),
     ]
 
 
@@ -86,6 +86,7 @@ _SIGNATURES = {
     "tsod_conv2d_dual_f32": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
     "tsod_bottleneck_wstream_bytes": (c_size_t, [c_int32, c_int32]),
+    "tsod_bottleneck_proj_wstream_bytes": (c_size_t, [c_int32, c_int32]),
     "tsod_bottleneck_fp16x2": (c_int, [POINTER(BottleneckDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tsod_stem_wfrag_bytes": (c_size_t, []),
     "tsod_stem_fp16x2": (c_int, [POINTER(StemDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -171,8 +172,8 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.tsod_version() != 241:
-            raise TsodError(f"{LIB_PATH} is version {l.tsod_version()}, this package binds version 241 of include/tsod.h: rebuild it "
+        if l.tsod_version() != 242:
+            raise TsodError(f"{LIB_PATH} is version {l.tsod_version()}, this package binds version 242 of include/tsod.h: rebuild it "
                             "(`make -C two_stage_object_detection_amd/csrc`)")
         _lib = l
     return _lib

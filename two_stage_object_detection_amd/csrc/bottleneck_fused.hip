@@ -3,6 +3,10 @@
 //     y1  = PReLU(BN1(conv1x1(x)))          Cin  -> 64      on the tile's pixels + a one-pixel halo
 //     y2  = PReLU(BN2(conv3x3(y1)))         64   -> 64      from LDS (y1 never leaves the CU)
 //     out = PReLU(BN3(conv1x1(y2)) + x)     64   -> Cout    (Cout == Cin: the identity blocks of layer1)
+// or, PROJ (models/resnet.py:114-116, the first block of layer1: a 1x1 projection shortcut at stride 1),
+//     out = PReLU(BN3(conv1x1(y2)) + BNd(conv1x1_d(x)))             as ONE stacked-K GEMM [y2 | x] . [W3 s3 | Wd sd]^T + (b3 + bd):
+//     the y2 chunks come from LDS, the x chunks of the tile's own pixels straight from L2 into MFMA fragments (the workgroup read
+//     them for conv1 a few microseconds earlier); no residual pass.
 //
 // Why: the three launches of such a block move 273 MB per image at 3x800x1333 (x read by conv1, y1 written and read, y2 written
 // and read, x read again as the residual, out written) for 3.6 GFLOP - layer1 is the one HBM-bound stage of the trunk
@@ -114,7 +118,7 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
 struct WFrag { u32x4 h[2], l[2]; };
 struct AFrag { u32x4 h, l; };
 
-template <int TH>
+template <int TH, bool PROJ = false>
 __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
     using G = Geo<TH>;
     constexpr int HALO = G::HALO, PB1 = G::PB1, PB2 = G::PB2, Y_PLANE = G::Y_PLANE, A_PLANE = G::A_PLANE, A_STAGE = G::A_STAGE,
@@ -152,7 +156,8 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
     // ---- weight stream: step s = 8 KB = [channel block cb][lane][chunk 0 hi | chunk 0 lo | chunk 1 hi | chunk 1 lo]: a lane's four
     // fragments of a step are 64 contiguous bytes, a wave's 4 KB - straight from L2 into registers (no LDS ring: no barrier per
     // step, and the weights are the same 272 KB for every workgroup of the launch: L2-resident), two steps ahead of their use
-    const int n_steps1 = p.Cin / 32, n_steps = n_steps1 + 18 + (p.Cout / 64) * 2;
+    // steps of one 64-channel slice of conv3: two over y2 and, PROJ, Cin / 32 more over x (the stacked projection shortcut)
+    const int n_steps1 = p.Cin / 32, sps = PROJ ? 2 + n_steps1 : 2, n_steps = n_steps1 + 18 + (p.Cout / 64) * sps;
     const u32x4 *wbase = reinterpret_cast<const u32x4 *>(p.wstream + cb * (W_STEP / 2) + lane * 64);
     auto w_load = [&](int s, WFrag &f) {
         if (s >= n_steps || ((p.dbg & 4) && s > 2)) return;
@@ -397,37 +402,83 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
             }
     };
     const int s3base = n_steps1 + 18;
-    // one 64-channel slice per iteration: its two weight steps sit in wf[0], wf[1]; the next slice's first step is requested into wf[2]
-    // at the start, its second into wf[0] as soon as that is dead (after two chunks); the slice ends by moving them into place
+  if constexpr (PROJ) {
+    // ---- stacked-K slices: steps 0, 1 contract y2 (LDS), steps 2 .. sps - 1 contract x (the tile's own pixels, from L2).  The two
+    // operands carry different scales (y2: this tile's, x: its tensor's): the accumulators change scale between them (a power of two:
+    // exact).  Weights rotate through wf[0 .. 2] by register moves as in conv1 (steps s, s + 1, s + 2).
+    unsigned xfo[3];                                     // byte offset in x of this lane's fragment pixel (channel 8 hh), kOOB outside the image
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int pidx = (pb0 + 2 * b) * 32 + j, pr = pidx >> 4, pc = pidx & 15;
+        const bool ok = b < nb2 && pidx < TH * TW && h0 + pr < p.H && w0 + pc < p.W;
+        xfo[b] = ok ? (unsigned)((((long)img * p.H + h0 + pr) * p.W + w0 + pc) * p.in_pitch + 8 * hh) * 4u : kOOB;
+    }
+    const float rescale = __uint_as_float((unsigned)(127 + e_x - e2) << 23);           // from 2^e2 y2 to 2^e_x x
+    const float sc3x = __uint_as_float((unsigned)(127 - e_x - p.w_exp3) << 23);
+    float4 xraw[2][3][2];                                // the x floats of one step (two chunks), requested one step ahead
+    auto x_frag_load = [&](int xs) {                     // x step xs: channels 32 xs + 16 c + 8 hh .. + 7
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const unsigned o = xfo[b] != kOOB ? xfo[b] + (unsigned)(32 * xs + 16 * c) * 4u : kOOB;
+                xraw[c][b][0] = bload4(rs_x, o);
+                xraw[c][b][1] = bload4(rs_x, o != kOOB ? o + 16u : kOOB);
+            }
+    };
     for (int q = 0; q < p.Cout / 64; ++q) {
 #pragma unroll
         for (int b = 0; b < 3; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
-        const unsigned chq = (unsigned)(q * 64) * 4u;                    // byte offset of the slice inside a pixel
-        w_load(s3base + 2 * q + 2, wf[2]);                               // (the weights first: in-order returns - they are needed first)
-        float4 res[3][4];                                                // the residual of this slice: requested before the MFMAs
+        const unsigned chq = (unsigned)(q * 64) * 4u;
+        const int sbase = s3base + q * sps;
+        for (int st = 0; st < sps; ++st) {
+            w_load(sbase + st + 2, wf[2]);
+            if (st < 2) {
+                if (st == 1) x_frag_load(0);             // the first x step flies under the second y2 step's MFMAs
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+                for (int c = 0; c < 2; ++c) {
+                    y2_frags(2 * st + c, af[c]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) res[b][i] = bload4(rs_x, (xpix[b][i] != kOOB && !(p.dbg & 2)) ? xpix[b][i] + chq : kOOB);
-        y2_frags(0, af[0]);
+                    for (int b = 0; b < 3; ++b)
+                        if (b < nb2) mfma3(acc[b], wf[0].h[c], wf[0].l[c], af[c][b].h, af[c][b].l);
+                }
+                if (st == 1) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            if (n == 2) w_load(s3base + 2 * q + 3, wf[0]);
-            if (n + 1 < 4) y2_frags(n + 1, af[(n + 1) & 1]);
+                    for (int b = 0; b < 3; ++b)
 #pragma unroll
-            for (int b = 0; b < 3; ++b)
-                if (b < nb2) mfma3(acc[b], wf[n >> 1].h[n & 1], wf[n >> 1].l[n & 1], af[n & 1][b].h, af[n & 1][b].l);
-            __builtin_amdgcn_sched_barrier(0);
+                        for (int e = 0; e < 16; ++e) acc[b][e] *= rescale;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        unsigned h0_, l0_, h1_, l1_, h2_, l2_, h3_, l3_;
+                        split2(xraw[c][b][0].x, xraw[c][b][0].y, a_scale, h0_, l0_);
+                        split2(xraw[c][b][0].z, xraw[c][b][0].w, a_scale, h1_, l1_);
+                        split2(xraw[c][b][1].x, xraw[c][b][1].y, a_scale, h2_, l2_);
+                        split2(xraw[c][b][1].z, xraw[c][b][1].w, a_scale, h3_, l3_);
+                        af[c][b].h = u32x4{h0_, h1_, h2_, h3_};
+                        af[c][b].l = u32x4{l0_, l1_, l2_, l3_};
+                    }
+                if (st + 1 < sps) x_frag_load(st - 1);   // the next x step's floats (their registers are free now)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        if (b < nb2) mfma3(acc[b], wf[0].h[c], wf[0].l[c], af[c][b].h, af[c][b].l);
+            }
+            wf[0] = wf[1];
+            wf[1] = wf[2];
         }
         const float4 s4 = *reinterpret_cast<const float4 *>(p.bn + 256 + q * 64 + cb * 32 + ep_q * 4);
         const float4 b4 = *reinterpret_cast<const float4 *>(p.bn + 256 + p.Cout + q * 64 + cb * 32 + ep_q * 4);
-        const float4 sv = make_float4(s4.x * sc3, s4.y * sc3, s4.z * sc3, s4.w * sc3);
+        const float4 sv = make_float4(s4.x * sc3x, s4.y * sc3x, s4.z * sc3x, s4.w * sc3x);
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
             if (b >= nb2) continue;
-            // accumulators -> patch: row j, channels 16 hh + 4 v .. + 3 (only this wave touches its patch: in-order LDS + the waits)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 chk = fmaf(acc[b][4 * v], 0.f, fmaf(acc[b][4 * v + 1], 0.f, fmaf(acc[b][4 * v + 2], 0.f, fmaf(acc[b][4 * v + 3], 0.f, chk))));
@@ -438,14 +489,14 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
             float4 t[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const float4 *>(patch + (ep_px + 8 * i) * P_PITCH + ep_q * 16);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (read before the next block overwrites the patch)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             float m4 = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float o0 = prelu(fmaf(t[i].x, sv.x, b4.x + res[b][i].x), p.slope);
-                const float o1 = prelu(fmaf(t[i].y, sv.y, b4.y + res[b][i].y), p.slope);
-                const float o2 = prelu(fmaf(t[i].z, sv.z, b4.z + res[b][i].z), p.slope);
-                const float o3 = prelu(fmaf(t[i].w, sv.w, b4.w + res[b][i].w), p.slope);
+                const float o0 = prelu(fmaf(t[i].x, sv.x, b4.x), p.slope);
+                const float o1 = prelu(fmaf(t[i].y, sv.y, b4.y), p.slope);
+                const float o2 = prelu(fmaf(t[i].z, sv.z, b4.z), p.slope);
+                const float o3 = prelu(fmaf(t[i].w, sv.w, b4.w), p.slope);
                 const float m = fmaxf(fmaxf(fabsf(o0), fabsf(o1)), fmaxf(fabsf(o2), fabsf(o3)));
                 m4 = fmaxf(m4, opix[b][i] != kOOB ? m : 0.f);
                 u32x4 o;
@@ -454,9 +505,69 @@ __global__ void __launch_bounds__(256, 2) bottleneck_kernel(const Params p) {
             }
             amax = fmaxf(amax, m4);
         }
-        wf[1] = wf[0];
-        wf[0] = wf[2];
     }
+  } else {
+      // one 64-channel slice per iteration: its two weight steps sit in wf[0], wf[1]; the next slice's first step is requested into wf[2]
+      // at the start, its second into wf[0] as soon as that is dead (after two chunks); the slice ends by moving them into place
+      for (int q = 0; q < p.Cout / 64; ++q) {
+  #pragma unroll
+          for (int b = 0; b < 3; ++b)
+  #pragma unroll
+              for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+          const unsigned chq = (unsigned)(q * 64) * 4u;                    // byte offset of the slice inside a pixel
+          w_load(s3base + 2 * q + 2, wf[2]);                               // (the weights first: in-order returns - they are needed first)
+          float4 res[3][4];                                                // the residual of this slice: requested before the MFMAs
+  #pragma unroll
+          for (int b = 0; b < 3; ++b)
+  #pragma unroll
+              for (int i = 0; i < 4; ++i) res[b][i] = bload4(rs_x, (xpix[b][i] != kOOB && !(p.dbg & 2)) ? xpix[b][i] + chq : kOOB);
+          y2_frags(0, af[0]);
+  #pragma unroll
+          for (int n = 0; n < 4; ++n) {
+              if (n == 2) w_load(s3base + 2 * q + 3, wf[0]);
+              if (n + 1 < 4) y2_frags(n + 1, af[(n + 1) & 1]);
+  #pragma unroll
+              for (int b = 0; b < 3; ++b)
+                  if (b < nb2) mfma3(acc[b], wf[n >> 1].h[n & 1], wf[n >> 1].l[n & 1], af[n & 1][b].h, af[n & 1][b].l);
+              __builtin_amdgcn_sched_barrier(0);
+          }
+          const float4 s4 = *reinterpret_cast<const float4 *>(p.bn + 256 + q * 64 + cb * 32 + ep_q * 4);
+          const float4 b4 = *reinterpret_cast<const float4 *>(p.bn + 256 + p.Cout + q * 64 + cb * 32 + ep_q * 4);
+          const float4 sv = make_float4(s4.x * sc3, s4.y * sc3, s4.z * sc3, s4.w * sc3);
+  #pragma unroll
+          for (int b = 0; b < 3; ++b) {
+              if (b >= nb2) continue;
+              // accumulators -> patch: row j, channels 16 hh + 4 v .. + 3 (only this wave touches its patch: in-order LDS + the waits)
+  #pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                  chk = fmaf(acc[b][4 * v], 0.f, fmaf(acc[b][4 * v + 1], 0.f, fmaf(acc[b][4 * v + 2], 0.f, fmaf(acc[b][4 * v + 3], 0.f, chk))));
+                  *reinterpret_cast<float4 *>(patch + j * P_PITCH + (16 * hh + 4 * v) * 4) =
+                      make_float4(acc[b][4 * v], acc[b][4 * v + 1], acc[b][4 * v + 2], acc[b][4 * v + 3]);
+              }
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              float4 t[4];
+  #pragma unroll
+              for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const float4 *>(patch + (ep_px + 8 * i) * P_PITCH + ep_q * 16);
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (read before the next block overwrites the patch)
+              float m4 = 0.f;
+  #pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                  const float o0 = prelu(fmaf(t[i].x, sv.x, b4.x + res[b][i].x), p.slope);
+                  const float o1 = prelu(fmaf(t[i].y, sv.y, b4.y + res[b][i].y), p.slope);
+                  const float o2 = prelu(fmaf(t[i].z, sv.z, b4.z + res[b][i].z), p.slope);
+                  const float o3 = prelu(fmaf(t[i].w, sv.w, b4.w + res[b][i].w), p.slope);
+                  const float m = fmaxf(fmaxf(fabsf(o0), fabsf(o1)), fmaxf(fabsf(o2), fabsf(o3)));
+                  m4 = fmaxf(m4, opix[b][i] != kOOB ? m : 0.f);
+                  u32x4 o;
+                  o.x = __float_as_uint(o0); o.y = __float_as_uint(o1); o.z = __float_as_uint(o2); o.w = __float_as_uint(o3);
+                  __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, opix[b][i] != kOOB ? opix[b][i] + chq : kOOB, 0, 0);
+              }
+              amax = fmaxf(amax, m4);
+          }
+          wf[1] = wf[0];
+          wf[0] = wf[2];
+      }
+  }
     if (p.range_flag != nullptr && __any(!(chk == 0.f)) && lane == 0) atomicOr(p.range_flag, 1);
     if (p.amax_out != nullptr) tsod_amax_commit(p.amax_out, amax, scr, tid, 256);
 }
@@ -468,11 +579,18 @@ extern "C" size_t tsod_bottleneck_wstream_bytes(int32_t Cin, int32_t Cout) {
     return (size_t)(Cin / 32 + 18 + (Cout / 64) * 2) * W_STEP;
 }
 
+extern "C" size_t tsod_bottleneck_proj_wstream_bytes(int32_t Cin, int32_t Cout) {
+    if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return 0;
+    return (size_t)(Cin / 32 + 18 + (Cout / 64) * (2 + Cin / 32)) * W_STEP;
+}
+
 extern "C" int tsod_bottleneck_fp16x2(const tsod_bottleneck_desc *d, const float *x, const void *wstream, const float *bn,
                                       float *out, tsod_stream_t stream) {
     TSOD_REQUIRE(d && x && wstream && bn && out, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0, TSOD_ERR_INVALID_ARG);
-    TSOD_REQUIRE(d->Cmid == CMID && d->Cin % 32 == 0 && d->Cin >= 32 && d->Cout % 64 == 0 && d->Cout == d->Cin, TSOD_ERR_UNSUPPORTED);
+    TSOD_REQUIRE(d->projection == 0 || d->projection == 1, TSOD_ERR_INVALID_ARG);
+    const bool proj = d->projection == 1;
+    TSOD_REQUIRE(d->Cmid == CMID && d->Cin % 32 == 0 && d->Cin >= 32 && d->Cout % 64 == 0 && (proj || d->Cout == d->Cin), TSOD_ERR_UNSUPPORTED);
     TSOD_REQUIRE(d->in_pitch >= d->Cin && d->out_pitch >= d->Cout && (d->in_pitch & 3) == 0 && (d->out_pitch & 3) == 0, TSOD_ERR_ALIGNMENT);
     TSOD_REQUIRE(tsod_aligned16(x) && tsod_aligned16(out) && tsod_aligned16(wstream) && tsod_aligned16(bn), TSOD_ERR_ALIGNMENT);
     TSOD_REQUIRE((reinterpret_cast<uintptr_t>(d->amax_in) & 63u) == 0 && (reinterpret_cast<uintptr_t>(d->amax_out) & 63u) == 0, TSOD_ERR_ALIGNMENT);
@@ -491,10 +609,10 @@ extern "C" int tsod_bottleneck_fp16x2(const tsod_bottleneck_desc *d, const float
         const int64_t tiles = (int64_t)d->N * ((d->W + TW - 1) / TW) * ((d->H + th - 1) / th);
         return (double)((tiles + 2 * cus - 1) / (2 * cus)) * mfma_slowest;
     };
-    const int n1 = d->Cin / 32, nq = d->Cout / 64;
+    const int n1 = d->Cin / 32, nq = d->Cout / 64, c3 = proj ? 4 + 2 * n1 : 4;           // chunks of a conv3 slice
     static const int force_th = [] { const char *e = getenv("TSOD_BN_TH"); return e ? atoi(e) : 0; }();
     const int TH = force_th == 8 || force_th == 10 ? force_th
-                   : (cost(8, 3 * (3 * 2 * n1 + 2 * 36 + 2 * 4 * nq)) < cost(10, 3 * (4 * 2 * n1 + 3 * 36 + 3 * 4 * nq)) ? 8 : 10);
+                   : (cost(8, 3 * (3 * 2 * n1 + 2 * 36 + 2 * c3 * nq)) < cost(10, 3 * (4 * 2 * n1 + 3 * 36 + 3 * c3 * nq)) ? 8 : 10);
     p.tiles_x = (d->W + TW - 1) / TW; p.tiles_y = (d->H + TH - 1) / TH;
     TSOD_REQUIRE((uint64_t)d->N * d->H * d->W * d->out_pitch * 4 < 0xFFFFFFF0ull && d->Cin % 64 == 0, TSOD_ERR_UNSUPPORTED);
     p.x_bytes = (unsigned)((uint64_t)d->N * d->H * d->W * d->in_pitch * 4);
@@ -506,7 +624,12 @@ extern "C" int tsod_bottleneck_fp16x2(const tsod_bottleneck_desc *d, const float
     p.dbg = dbg;
     const int64_t grid = (int64_t)d->N * p.tiles_x * p.tiles_y;
     TSOD_REQUIRE(grid < 0x7FFFFFFF, TSOD_ERR_UNSUPPORTED);
-    if (TH == 8) hipLaunchKernelGGL(bottleneck_kernel<8>, dim3((unsigned)grid), dim3(256), 0, tsod_stream(stream), p);
-    else hipLaunchKernelGGL(bottleneck_kernel<10>, dim3((unsigned)grid), dim3(256), 0, tsod_stream(stream), p);
+    if (proj) {
+        if (TH == 8) hipLaunchKernelGGL((bottleneck_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, tsod_stream(stream), p);
+        else hipLaunchKernelGGL((bottleneck_kernel<10, true>), dim3((unsigned)grid), dim3(256), 0, tsod_stream(stream), p);
+    } else {
+        if (TH == 8) hipLaunchKernelGGL((bottleneck_kernel<8, false>), dim3((unsigned)grid), dim3(256), 0, tsod_stream(stream), p);
+        else hipLaunchKernelGGL((bottleneck_kernel<10, false>), dim3((unsigned)grid), dim3(256), 0, tsod_stream(stream), p);
+    }
     return tsod_launch_status();
 }

@@ -83,20 +83,33 @@ class FusedShortcutConv:
 
 
 class FusedBottleneckWeights:
-    """An identity-shortcut bottleneck (models/resnet.py:57-76, stride 1, no downsample) packed for tsod_bottleneck_fp16x2: the
-    three convs' weights as one stream in consumption order, the three folded BatchNorms as one vector, the shared PReLU slope."""
+    """A bottleneck with 64 mid channels at stride 1 (models/resnet.py:57-76) packed for tsod_bottleneck_fp16x2: the three convs'
+    weights as one stream in consumption order, the three folded BatchNorms as one vector, the shared PReLU slope.  With a
+    projection shortcut (``blk.downsample``: :114-116, layer1's first block) conv3 and the shortcut are ONE stacked-K matrix
+    [W3 s3 | Wd sd] (both BatchNorm scales folded in f64, rounded once - as FusedShortcutConv does for the three-launch form),
+    the vector's s3 is all ones and its b3 the two shifts added up."""
 
     def __init__(self, blk, device):
         from . import hip_ops
         c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
         self.cin, self.cmid, self.cout = c1.in_channels, c1.out_channels, c3.out_channels
+        self.projection = blk.downsample is not None
         w1 = c1.weight.detach().float().to(device).view(self.cmid, self.cin)
         w2 = hip_ops.pack_conv_weight(c2.weight.detach().float().to(device))            # [64, 3, 3, 64]
-        w3 = c3.weight.detach().float().to(device).view(self.cout, self.cmid)
-        self.stream, self.w_exps = hip_ops.pack_bottleneck_wstream(w1, w2, w3)
         bn = []
-        for m in (blk.bn1, blk.bn2, blk.bn3):
+        for m in (blk.bn1, blk.bn2):
             bn.extend(fold_bn(m))
+        s3, b3 = fold_bn(blk.bn3)
+        if self.projection:
+            sd, bd = fold_bn(blk.downsample[1])
+            w3 = c3.weight.detach().double().cpu().flatten(1) * s3.double().view(-1, 1)                     # [Cout, 64]
+            wd = blk.downsample[0].weight.detach().double().cpu().flatten(1) * sd.double().view(-1, 1)      # [Cout, Cin]
+            w3 = torch.cat([w3, wd], dim=1).float().contiguous().to(device)
+            bn.extend([torch.ones_like(s3), (b3.double() + bd.double()).float()])
+        else:
+            w3 = c3.weight.detach().float().to(device).view(self.cout, self.cmid)
+            bn.extend([s3, b3])
+        self.stream, self.w_exps = hip_ops.pack_bottleneck_wstream(w1, w2, w3, projection=self.projection)
         self.bn = torch.cat(bn).to(device)
         self.slope = prelu_slope(blk.relu)
         if not torch.cuda.is_current_stream_capturing():
@@ -388,9 +401,11 @@ class Plan:
         """x [N,H,W,Cin] -> out [N,H,W,Cout]: conv1 + conv2 + conv3 + identity of a bottleneck as ONE launch (fp16x2; the input's
         scale from its range words when the plan keeps them, the intermediates' from each tile's own abs-max)."""
         N, H, W, P = x.shape
-        assert tuple(out.shape[:3]) == (N, H, W) and fb.cin == fb.cout
+        proj = bool(getattr(fb, "projection", False))
+        assert tuple(out.shape[:3]) == (N, H, W) and (proj or fb.cin == fb.cout)
         d = _ffi.BottleneckDesc()
         d.N, d.H, d.W, d.Cin, d.in_pitch, d.Cmid, d.Cout, d.out_pitch = N, H, W, fb.cin, P, fb.cmid, fb.cout, out.shape[3]
+        d.projection = 1 if proj else 0
         d.slope = float(fb.slope)
         for k in range(3):
             d.w_exp[k] = int(fb.w_exps[k])
@@ -400,9 +415,9 @@ class Plan:
         args = [byref(d), ptr(x), ptr(fb.stream), ptr(fb.bn), ptr(out)]
         self.steps.append([lib().tsod_bottleneck_fp16x2, args])
         px = N * H * W
-        flops = 2 * px * (fb.cin * fb.cmid + 9 * fb.cmid * fb.cmid + fb.cmid * fb.cout)
-        # what the block must move however it is computed: x in, out out, the weights (the residual is x again: counted once)
-        alg = 4 * (px * fb.cin + px * fb.cout + fb.cin * fb.cmid + 9 * fb.cmid * fb.cmid + fb.cmid * fb.cout)
+        flops = 2 * px * (fb.cin * fb.cmid + 9 * fb.cmid * fb.cmid + fb.cmid * fb.cout + (fb.cin * fb.cout if proj else 0))
+        # what the block must move however it is computed: x in, out out, the weights (the residual / shortcut input is x again: counted once)
+        alg = 4 * (px * fb.cin + px * fb.cout + fb.cin * fb.cmid + 9 * fb.cmid * fb.cmid + fb.cmid * fb.cout + (fb.cin * fb.cout if proj else 0))
         st = FusedStep(name, self.steps[-1][0], args, d, flops, alg, x=x)
         self.fused_steps.append(st)
         self.gemm_steps.append(st)

@@ -231,9 +231,11 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, *, stride=1, pad=0, kw_
     return out
 
 
-def pack_bottleneck_wstream(w1: torch.Tensor, w2: torch.Tensor, w3: torch.Tensor):
+def pack_bottleneck_wstream(w1: torch.Tensor, w2: torch.Tensor, w3: torch.Tensor, projection: bool = False):
     """The weight stream of tsod_bottleneck_fp16x2 (include/tsod.h): w1 [64, Cin], w2 [64, 3, 3, 64] (packed conv layout:
     [Cout][KH][KW][Cin]), w3 [Cout, 64], f32 -> (uint8 tensor of tsod_bottleneck_wstream_bytes, (e1, e2, e3)).
+    ``projection``: w3 is the stacked [Cout, 64 + Cin] matrix [W3 s3 | Wd sd] of desc.projection == 1 (2 + Cin / 32 steps per 64
+    output channels, one exponent for the whole matrix).
     Pure index arithmetic on the three matrices (done once per model; the fp16 roundings are torch's round-to-nearest-even,
     the same bits as the device's v_cvt_pk_f16_f32).  A step (64 output channels x 32 k) is stored as the MFMA fragments the
     kernel's lanes load: [channel block cb (2)][lane (64) = 32 hh + j][chunk c (2)][hi | lo][8 k] fp16, where lane (j, hh) holds
@@ -260,21 +262,23 @@ def pack_bottleneck_wstream(w1: torch.Tensor, w2: torch.Tensor, w3: torch.Tensor
     s1 = steps(w1.reshape(64, cin), e1)
     # conv2: step = (tap, channel half): K order of the packed layout is (kh, kw, ci), so k = 32 * (2 tap + half) already
     s2 = steps(w2.reshape(64, 9 * 64), e2)
-    s3 = steps(w3.reshape(cout, 64), e3)                                     # row blocks of 64 output channels, 2 k-steps each
+    s3 = steps(w3.reshape(cout, 64 + cin if projection else 64), e3)         # row blocks of 64 output channels, 2 (+ Cin / 32) k-steps each
     stream = torch.cat([s1, s2, s3], dim=0).contiguous().view(-1)
-    assert stream.numel() == lib().tsod_bottleneck_wstream_bytes(cin, cout)
+    assert stream.numel() == (lib().tsod_bottleneck_proj_wstream_bytes if projection else lib().tsod_bottleneck_wstream_bytes)(cin, cout)
     return stream, (e1, e2, e3)
 
 
 def bottleneck_fused(x: torch.Tensor, wstream: torch.Tensor, w_exps, bn: torch.Tensor, cout: int, slope: float, *, out=None,
-                     a_scale_exp=4, amax_in=None, amax_out=None, range_flag=None) -> torch.Tensor:
-    """tsod_bottleneck_fp16x2 on an NHWC tensor x [N,H,W,P] (channels [0, cout) are the block's input): see include/tsod.h."""
+                     a_scale_exp=4, amax_in=None, amax_out=None, range_flag=None, cin=None) -> torch.Tensor:
+    """tsod_bottleneck_fp16x2 on an NHWC tensor x [N,H,W,P] (channels [0, cout) are the block's input; ``cin``: the projection
+    form, channels [0, cin) in, cout out): see include/tsod.h."""
     require_cuda(x, "bottleneck_fused")
     N, H, W, P = x.shape
     if out is None:
         out = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
     d = _ffi.BottleneckDesc()
-    d.N, d.H, d.W, d.Cin, d.in_pitch, d.Cmid, d.Cout, d.out_pitch = N, H, W, cout, P, 64, cout, out.shape[3]
+    d.N, d.H, d.W, d.Cin, d.in_pitch, d.Cmid, d.Cout, d.out_pitch = N, H, W, cout if cin is None else cin, P, 64, cout, out.shape[3]
+    d.projection = 0 if cin is None else 1
     d.slope = float(slope)
     for k in range(3):
         d.w_exp[k] = int(w_exps[k])

@@ -34,6 +34,18 @@ class _ResidualBlock(nn.Module):
         dev = plan.device
         slope = prelu_slope(self.relu)
         identity = x
+        # the whole block as ONE launch (tsod_bottleneck_fp16x2): 64 mid channels, stride 1 - layer1, the HBM-bound stage of the trunk
+        # (the 64-channel intermediates stay in LDS): the identity blocks layer1.1 / layer1.2 and (round 5) the block in front of
+        # them, whose shortcut is a 1x1 projection at stride 1 (layer1.0): conv3 + shortcut as one stacked-K GEMM inside the launch
+        if getattr(plan, "fuse_bottleneck", False) and len(self._stage_names) == 3:
+            ident = self.downsample is None and self.conv1.in_channels == self.conv3.out_channels
+            proj = (self.downsample is not None and len(self.downsample) == 2 and isinstance(self.downsample[0], nn.Conv2d)
+                    and self.downsample[0].kernel_size == (1, 1) and self.downsample[0].stride == (1, 1) and self.downsample[0].groups == 1)
+            if ((ident or proj) and self.conv1.out_channels == 64 and self.conv2.groups == 1 and self.conv2.stride == (1, 1)
+                    and self.conv1.in_channels % 64 == 0 and self.conv3.out_channels % 64 == 0):
+                fb = plan.packed(f"{name}.fused", lambda: FusedBottleneckWeights(self, dev))
+                out = plan.pool.alloc((x.shape[0], x.shape[1], x.shape[2], fb.cout))
+                return plan.bottleneck(fb, x, out, name=f"{name}.fused")
         # projection shortcut + last 1x1 conv as ONE stacked-K GEMM (engine.FusedShortcutConv): one launch, no shortcut tensor
         # written and re-read as residual.  Needs a 1x1 last conv (Bottleneck) and channel counts the K-steps divide.
         last_name, last_bn = self._stage_names[-1]
@@ -47,14 +59,6 @@ class _ResidualBlock(nn.Module):
                                                                       act=ACT_NONE))
             oh, ow = pc.out_hw(x.shape[1], x.shape[2])
             identity = plan.conv(pc, x, plan.pool.alloc((x.shape[0], oh, ow, pc.cout)), name=f"{name}.downsample")
-        # the whole block as ONE launch (tsod_bottleneck_fp16x2): identity shortcut, 64 mid channels, stride 1 - layer1.1 / layer1.2,
-        # the HBM-bound stage of the trunk (the 64-channel intermediates stay in LDS)
-        if (getattr(plan, "fuse_bottleneck", False) and self.downsample is None and len(self._stage_names) == 3
-                and self.conv1.out_channels == 64 and self.conv2.groups == 1 and self.conv2.stride == (1, 1)
-                and self.conv1.in_channels == self.conv3.out_channels and self.conv1.in_channels % 64 == 0):
-            fb = plan.packed(f"{name}.fused", lambda: FusedBottleneckWeights(self, dev))
-            out = plan.pool.alloc((x.shape[0], x.shape[1], x.shape[2], fb.cout))
-            return plan.bottleneck(fb, x, out, name=f"{name}.fused")
         cur = x
         last = len(self._stage_names) - 1
         for i, (cname, bname) in enumerate(self._stage_names):

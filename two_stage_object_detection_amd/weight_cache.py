@@ -29,7 +29,7 @@ import torch
 
 from ._ffi import TsodError
 
-FORMAT = 3
+FORMAT = 4
 
 
 # ----------------------------------------------------------------------------- hashing
@@ -72,7 +72,7 @@ def _to_state(obj):
     if isinstance(obj, (tuple, list)):
         return {"__tuple__": [_to_state(o) for o in obj]}
     name = type(obj).__name__
-    if name in ("PackedConv", "_RawConv", "FusedShortcutConv"):
+    if name in ("PackedConv", "_RawConv", "FusedShortcutConv", "FusedBottleneckWeights", "FusedStemWeights"):
         return {"__obj__": name, **{k: _to_state(v) for k, v in vars(obj).items()}}
     raise TsodError(f"weight cache: cannot serialise a {name}")
 
@@ -85,9 +85,10 @@ def _from_state(st, device):
     if isinstance(st, dict) and "__tuple__" in st:
         return tuple(_from_state(o, device) for o in st["__tuple__"])
     if isinstance(st, dict) and "__obj__" in st:
-        from .engine import FusedShortcutConv, PackedConv
+        from .engine import FusedBottleneckWeights, FusedShortcutConv, FusedStemWeights, PackedConv
         from .models.hardnet import _RawConv
-        cls = {"PackedConv": PackedConv, "_RawConv": _RawConv, "FusedShortcutConv": FusedShortcutConv}[st["__obj__"]]
+        cls = {"PackedConv": PackedConv, "_RawConv": _RawConv, "FusedShortcutConv": FusedShortcutConv,
+               "FusedBottleneckWeights": FusedBottleneckWeights, "FusedStemWeights": FusedStemWeights}[st["__obj__"]]
         obj = cls.__new__(cls)                       # no packing work: the attributes ARE the packed form
         for k, v in st.items():
             if k != "__obj__":
