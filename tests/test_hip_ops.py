@@ -790,7 +790,7 @@ def test_dma_conv_tiles_at_full_layer_sizes(ops, dev, shape):
     ref = ops.conv2d_nhwc(x, w, pad=k // 2, tile=3, split_k=1)                       # f32 MFMA, whole tiles
     tol = 3e-6 * math.sqrt(Cin * k * k) * 2 + 2e-5
     for tile in DMA_TILE_IDS:
-        prec = 2 if tile == 23 else 1                    # (d192x128 exists in fp16x2 only)
+        prec = 2 if tile in (23, 24) else 1              # (d192x128, d64x128k64 exist in fp16x2 only)
         for split in (1, -1, -2, 3):
             y = ops.conv2d_nhwc(x, w, pad=k // 2, tile=tile, split_k=split, precision=prec)
             assert (y - ref).abs().max().item() <= tol, (tile, split)
