@@ -508,6 +508,37 @@ def test_in_flight_detector_returns_each_requests_own_result(dev, synth):
         server.result(0)                                          # slot 0 has been reused since
 
 
+def test_in_flight_replays_survive_host_copies_between_them(dev):
+    """Several graphs in flight, the fp16x2 arithmetic (range words), and HOST COPIES of a slot's outputs between the replays (what
+    any client does with its results): every later replay of every slot must still be the eager forward bit for bit.  Round 5 found
+    that it was not (the bench's parity leg, then tmp_gpu/debug_inflight*.py; round 4's library too): the range words' reset was a
+    captured hipMemsetAsync node, after blit copies to the host a slot's words were no longer what the reset should have left, and
+    range words only ever grow - one stale giant word scales every fp16x2 layer behind it to nothing, for good.  The reset is a
+    kernel of the library now."""
+    from two_stage_object_detection_amd.serving import InFlightDetector
+    from two_stage_object_detection_amd.testing import synthetic_detector
+    model, _ = synthetic_detector("resnet50", num_classes=20, seed=0)
+    model = model.to(dev).eval()
+    model.extractor.set_conv_precision("fp16x2")
+    model.extractor.set_structure({"fuse_stem": True, "fuse_bottleneck": True})
+    x = _img((1, 3, 480, 640), seed=17).to(dev)
+    with torch.inference_mode():
+        ref = [o.clone() for o in model(x)]
+        model.raise_if_error()
+        for trial in range(2):
+            server = InFlightDetector(model, x, depth=4)
+            for rnd in range(5):
+                ts = [server.submit() for _ in range(4)]
+                for t in ts:
+                    outs = server.result(t)
+                    for a, b in zip(outs[:3], ref[:3]):
+                        assert torch.equal(a, b), (trial, rnd, t % 4, float((a - b).abs().max()))
+                    host = [o.cpu() for o in outs[:4]]                  # strided views: a contiguous device copy + a blit to the host each
+                    assert torch.isfinite(host[2]).all()
+            server.drain()
+    model.extractor.set_structure(None)
+
+
 def test_in_flight_detector_blames_the_request_at_fault(dev):
     """Every in-flight slot reports into a range word of its own: a request with a non-finite pixel raises at ITS result(),
     whichever ticket is collected first, and the clean requests around it keep their results (one shared word used to hand the

@@ -438,10 +438,23 @@ extern "C" int tsod_nchw_to_nhwc_f32(const float *in, int32_t N, int32_t C, int3
     return tsod_nchw_to_nhwc_amax_f32(in, N, C, H, W, out, out_pitch, C_pad, nullptr, stream);
 }
 
+// The reset is a KERNEL of this library, not hipMemsetAsync (round 5).  Captured into a HIP graph a memset becomes a memset node whose
+// fill runs on the runtime's blit path; with several such graphs replayed on several streams and host copies (blit copies) in
+// between, a slot's words were found NOT zeroed - range words only ever grow (atomic max), so one stale giant word scales every
+// fp16x2 layer behind it to nothing for good (scripts: tmp_gpu/debug_inflight*.py; the same with round 4's
+// library; never with the words switched off).  A kernel node carries its arguments by value and zeroes exactly the 64 words of
+// every tensor (one thread per word), which is all a reader ever looks at.
+__global__ void __launch_bounds__(256) amax_reset_kernel(unsigned *__restrict__ words, int n_words) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t < n_words) words[(size_t)(t / TSOD_AMAX_WORDS) * (TSOD_AMAX_BYTES / 4) + (size_t)(t % TSOD_AMAX_WORDS) * TSOD_AMAX_STRIDE_WORDS] = 0u;
+}
+
 extern "C" int tsod_amax_reset(uint32_t *words, int32_t n_tensors, tsod_stream_t stream) {
     TSOD_REQUIRE(words && n_tensors > 0, TSOD_ERR_INVALID_ARG);
     TSOD_REQUIRE((reinterpret_cast<uintptr_t>(words) & 63u) == 0, TSOD_ERR_ALIGNMENT);
-    return hipMemsetAsync(words, 0, (size_t)n_tensors * TSOD_AMAX_BYTES, tsod_stream(stream)) == hipSuccess ? TSOD_OK : TSOD_ERR_LAUNCH;
+    const int n_words = n_tensors * TSOD_AMAX_WORDS;
+    hipLaunchKernelGGL(amax_reset_kernel, dim3((n_words + 255) / 256), dim3(256), 0, tsod_stream(stream), words, n_words);
+    return tsod_launch_status();
 }
 
 extern "C" int tsod_absmax_f32(const float *x, int64_t n, uint32_t *amax_out, tsod_stream_t stream) {
