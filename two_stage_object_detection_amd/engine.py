@@ -684,11 +684,24 @@ class Plan:
                 best = min(close, key=lambda c: (beyond_l2(c[1], c[2], c[3]), c[0]))
             st.choose(best[1], best[2], best[3])
             n_short = max(1, int(in_sequence), int(keep_shortlist))
-            short = list(timed[:n_short])
-            if n_short > 1:                                       # (the refinements see every arithmetic's best too)
+            if n_short > 1:
+                # the shortlist of the second looks: the fastest candidates of the first look, at most TWO schedules per (tile,
+                # arithmetic) - a tile whose repetitions keep its operands hot takes every place with its K schedules otherwise, and
+                # the look inside the sequence (cold weights, the input where its producer left it) then has nothing else to choose
+                # from (round 5: d64x128k64, 18.5 us isolated / 26.4 in sequence on layer3's 1x1 convs, had pushed d128x128k32 out
+                # of the list on 16 layers) - plus every arithmetic's best
+                short, per = [], {}
+                for c in timed:
+                    if per.get((c[1], c[3]), 0) < 2:
+                        short.append(c)
+                        per[(c[1], c[3])] = per.get((c[1], c[3]), 0) + 1
+                    if len(short) >= n_short:
+                        break
                 for pr in sorted({c[3] for c in timed}):
                     if all(c[3] != pr for c in short):
                         short.append(next(c for c in timed if c[3] == pr))
+            else:
+                short = list(timed[:1])
             shortlist.append([(tile, split, prec) for _, tile, split, prec in short])
             by = {}
             for t_, tile, split, prec in timed:                      # (sorted: the first of an arithmetic is its fastest)
