@@ -173,6 +173,14 @@ int tsod_amax_reset(uint32_t *words, int32_t n_tensors, tsod_stream_t stream);
 /* abs-max of n floats into the words (for tensors no libtsod kernel produced: an image handed over in NHWC(4) layout) */
 int tsod_absmax_f32(const float *x, int64_t n, uint32_t *amax_out, tsod_stream_t stream);
 
+/* A device word the HOST can read without a device call (serving: one range-flag read per request, nets/.. serving.py).
+ * tsod_host_mapped_pointer: the device-side address of page-locked, mapped host memory (hipHostMalloc, torch's pin_memory()) -
+ * a query, made once; TSOD_ERR_UNSUPPORTED when the memory is not mapped into the current device.  tsod_word_publish_i32: one
+ * thread stores *src_device to that address, stream-ordered and capturable (a kernel node, no blit); the host reads its own
+ * memory once the forward's event has completed. */
+int tsod_host_mapped_pointer(void *host, void **device);
+int tsod_word_publish_i32(const int32_t *src_device, int32_t *dst_mapped, tsod_stream_t stream);
+
 /* Packed weight layout Wp: [Cout][KH][KW][Cin] f32 (k = (kh*KW + kw)*Cin + ci, ci running over
  * the concatenated segments).  tsod_pack_conv_weight_f32 converts torch's [Cout][Cin_src][KH][KW]:
  * Cin >= Cin_src, extra input channels get zero weights (used to pad 3 -> 4 channels in the

@@ -572,6 +572,10 @@ def test_in_flight_detector_blames_the_request_at_fault(dev):
     # plans of one owner on one device share the words' tensor; the words belong to the plan's own device
     plan = model.extractor._plan_for(xs[0], 1)
     assert plan.range_flag.device == xs[0].device and plan.range_flag.numel() == 1
+    # result() read the HOST's copy of the words (published by a one-thread kernel at the end of every forward: no device-to-host
+    # copy per request): it exists, is page-locked, and is clean again after the raise
+    mirror = model.extractor._range_mirror(xs[0].device)
+    assert mirror is not None and mirror[0].is_pinned() and int(mirror[0].abs().sum()) == 0
 
 
 @pytest.mark.parametrize("backbone", ["resnet50", "hardnet39"])

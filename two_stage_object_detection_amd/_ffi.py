@@ -104,6 +104,8 @@ _SIGNATURES = {
     "tsod_nchw_to_nhwc_amax_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "tsod_absmax_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "tsod_amax_reset": (c_int, [c_void_p, c_int32, c_void_p]),
+    "tsod_host_mapped_pointer": (c_int, [c_void_p, c_void_p]),
+    "tsod_word_publish_i32": (c_int, [c_void_p, c_void_p, c_void_p]),
     "tsod_gconv3x3_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                   c_int32, c_int32, c_float, c_void_p, c_int32, c_void_p]),
     "tsod_gconv1x1_pair_f32": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),

@@ -978,6 +978,28 @@ class PlanOwner:
         i = int(slot) % self.RANGE_WORDS
         return t[i:i + 1]
 
+    def _range_mirror(self, device):
+        """(page-locked host int32[64], its device-side address) - the host's copy of this device's range words, one per in-flight
+        slot, written by ``publish_range_word`` at the end of a forward: ``range_flag_raised(slot, host=True)`` then costs a read
+        of host memory instead of a device-to-host copy per request.  None where the memory cannot be mapped into the device."""
+        mirrors = self.__dict__.setdefault("_range_mirrors", {})
+        device = torch.device(device)
+        if device not in mirrors:
+            from ctypes import c_void_p
+            host = torch.zeros(self.RANGE_WORDS, dtype=torch.int32).pin_memory()
+            dptr = c_void_p(0)
+            with torch.cuda.device(device):
+                rc = lib().tsod_host_mapped_pointer(host.data_ptr(), byref(dptr))
+            mirrors[device] = (host, int(dptr.value)) if rc == 0 and dptr.value else None
+        return mirrors[device]
+
+    def publish_range_word(self, plan) -> None:
+        """Copy the plan's range word to the host mirror (one thread, stream-ordered, capturable): last launch of a detector forward."""
+        m = self._range_mirror(plan.device)
+        if m is not None:
+            slot = int(getattr(plan, "slot", 0)) % self.RANGE_WORDS
+            check(lib().tsod_word_publish_i32(ptr(plan.range_flag), m[1] + 4 * slot, stream_ptr()), "word_publish")
+
     def raise_if_error(self, slot=None):
         """Surface what the fp16x2 launches of ANY plan of this owner (``slot``: of that in-flight slot only) reported since the
         last call (evicted plans included: the words belong to the owner): a launch that ended with non-finite accumulators -
@@ -991,11 +1013,23 @@ class PlanOwner:
                 with torch.inference_mode():
                     v.zero_()
         if bad:
+            for m in self.__dict__.get("_range_mirrors", {}).values():     # (the host's copies follow)
+                if m is not None:
+                    if slot is None:
+                        m[0].zero_()
+                    else:
+                        m[0][int(slot) % self.RANGE_WORDS] = 0
             raise TsodError("fp16x2: a conv layer ended with non-finite accumulators - non-finite input (or, without range words, "
                             f"an activation beyond +-{65504 // (1 << FP16X2_A_SCALE_EXP)}); its outputs are garbage")
 
-    def range_flag_raised(self, slot=None) -> bool:
-        """The words as they are now (one small device read): True once a launch that has COMPLETED reported (serving.result())."""
+    def range_flag_raised(self, slot=None, host=False) -> bool:
+        """The words as they are now (one small device read): True once a launch that has COMPLETED reported (serving.result()).
+        ``host`` = True (with ``slot``): read the host mirror instead - what the slot's last COMPLETED forward published at its end
+        (``publish_range_word``): no device call at all; falls back to the device read where there is no mirror."""
+        if host and slot is not None:
+            mirrors = self.__dict__.get("_range_mirrors", {})
+            if mirrors and all(m is not None for m in mirrors.values()):
+                return any(int(m[0][int(slot) % self.RANGE_WORDS]) != 0 for m in mirrors.values())
         for t in self.__dict__.get("_range_words", {}).values():
             v = t if slot is None else t[int(slot) % self.RANGE_WORDS:int(slot) % self.RANGE_WORDS + 1]
             if bool(v.cpu().any()):
@@ -1015,6 +1049,7 @@ class PlanOwner:
         self.__dict__["_packed_cache"] = {}
         self.__dict__.setdefault("_a_exps", {}).clear()
         self.__dict__["_range_words"] = {}       # (per device; the plans that pointed at the old words are gone with them)
+        self.__dict__["_range_mirrors"] = {}
         self.__dict__["weights_version"] = self.__dict__.get("weights_version", 0) + 1
 
     def _bump_version(self):
@@ -1026,7 +1061,7 @@ class PlanOwner:
 
     def __getstate__(self):                       # copy.deepcopy / pickling: plans hold ctypes objects and raw pointers
         st = self.__dict__.copy()
-        st["_plans"], st["_packed_cache"], st["_range_words"] = OrderedDict(), {}, {}
+        st["_plans"], st["_packed_cache"], st["_range_words"], st["_range_mirrors"] = OrderedDict(), {}, {}, {}
         return st
 
     def _cached_plan(self, key, build: Callable):
@@ -1040,6 +1075,7 @@ class PlanOwner:
                 slot = key[2] if isinstance(key, tuple) and len(key) > 2 and isinstance(key[2], int) else 0
                 flag = self._range_word(plan.device, slot)
                 assert flag.device == plan.device
+                plan.slot = slot
                 plan.a_exps = shared
                 plan.range_flag = flag
                 plan.on_calibrated = self._bump_version           # (a graph captured at detector level holds the old exponents)

@@ -93,6 +93,9 @@ class FasterRCNN(nn.Module):
                 roi_indices = self._roi_indices(x.shape[0], x.device)
                 roi_cls_locs, roi_scores = self.head.forward_nhwc(feat, rois, roi_indices, tuple(x.shape[2:]), feat_amax=feat_amax,
                                                                   range_flag=flag)
+                # the slot's range word -> the host's copy (one thread; serving.result() then needs no device call to see whether
+                # THIS forward ended with non-finite accumulators)
+                self.extractor.publish_range_word(self.extractor._plan_for(x, slot))
             return roi_cls_locs, roi_scores, rois, roi_indices
         elif mode == "extractor":
             return self.extractor.forward(x)

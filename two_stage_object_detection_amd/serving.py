@@ -91,7 +91,9 @@ class InFlightDetector:
         # GPU's critical path).  Every slot has its own plan and its own word, so a set word means THIS step ran an fp16x2 layer
         # into non-finite accumulators (non-finite input): its outputs are garbage - never hand them out as valid - while the
         # other requests in flight are unaffected and keep their results.
-        if self.model.extractor.range_flag_raised(slot):
+        # (host=True: the word as the slot's forward published it into page-locked host memory at its end - a read of host memory, no
+        #  device-to-host copy per request; the raise itself reads and clears the device word)
+        if self.model.extractor.range_flag_raised(slot, host=True):
             self.model.extractor.raise_if_error(slot)
         return self._outputs[slot]
 
