@@ -316,6 +316,7 @@ def pmc_traffic(args, tiles, n_launches):
     try:
         tiles_path = os.path.join(work, "tiles.json")
         json.dump({"serial": tiles["serial"], "fuse_bottleneck": bool(tiles.get("fuse_bottleneck", False)),
+                   "fuse_projection": bool(tiles.get("fuse_projection", False)),
                    "fuse_stem": bool(tiles.get("fuse_stem", False))}, open(tiles_path, "w"))
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -460,7 +461,7 @@ def rehearse_cpu(args, rank, world):
     # the start-up protocol of the real run: rank 0 "tunes" (here: fabricates a table only it knows), every rank gets it
     t0 = time.perf_counter()
     mine = {"serial": [["conv1", 14, -1, 1], ["layer1.0.conv1", 8, 1, 1]], "heads": {"rpn": {"8x25x42": [3, 1, 1]}, "head": {"2400": [8, 2, 1]}},
-            "fuse_stem": True, "fuse_bottleneck": False,
+            "fuse_stem": True, "fuse_bottleneck": False, "fuse_projection": False,
             "parity_budget": {"budget_px": 5e-4, "before_px": 9e-4, "after_px": 4e-4, "demoted": ["layer3.0.conv1"], "held": True},
             "tuned_by_rank": 0} if rank == 0 else {"tuned_by_rank": rank}
     tiles = broadcast_json(mine, rank, world)
@@ -814,7 +815,7 @@ def main(argv=None):
                          "algorithmic_bytes_per_launch": round(algo_bytes / len(conv_ms)),
                          "traffic_over_algorithmic": None if traffic is None else round(traffic * len(conv_ms) / algo_bytes, 3),
                          "kernel": f"conv_igemm_kernel / conv_dma_kernel (implicit GEMM; per layer f32 MFMA, bf16x3 or fp16x2 MFMA, register-staged or "
-                                   f"fed by LDS-DMA)" + (f" + bottleneck_kernel ({n_fused} identity bottlenecks of layer1 as one launch each)" if n_fused else "")
+                                   f"fed by LDS-DMA)" + (f" + bottleneck_kernel ({n_fused} bottlenecks of layer1 as one launch each)" if n_fused else "")
                                    + (" + stem_kernel (conv1 + bn1 + PReLU + max pool from the NCHW images as one launch)" if has_stem else "")
                                    + f", {len(conv_ms)} launches per forward",
                          "schedule": "serial", "flops_per_forward": conv_flops,

@@ -60,7 +60,7 @@ def test_detector_with_the_committed_autotuned_tile_tables(dev, r50, table):
     blob = json.load(open(table))
     tiles = blob if key is None else blob[key]
     # (the comparison legs' tables "f32" / "bf16x3" are always recorded on the plain structure)
-    structure = {k: bool(blob.get(k, False)) for k in ("fuse_bottleneck", "fuse_stem")} if key in ("serial", "in_flight") else {}
+    structure = {k: bool(blob.get(k, False)) for k in ("fuse_bottleneck", "fuse_projection", "fuse_stem")} if key in ("serial", "in_flight") else {}
     xg = x.to(dev)
     legacy = any(r[0].endswith(".downsample") for r in tiles)       # tables recorded before the shortcut fusion: 53 convs
     with torch.inference_mode():
@@ -71,9 +71,9 @@ def test_detector_with_the_committed_autotuned_tile_tables(dev, r50, table):
             model.extractor.set_structure(structure)                    # (round 4 on: a table belongs to a launch structure)
             model(xg)
             plan = model.extractor._plan_for(xg)
-            # (round 5: fuse_bottleneck covers all of layer1 - 9 convs in 3 launches; round 4's tables were made for 6 in 2)
-            assert len(plan.conv_steps) == ((53 if legacy else 49) - (9 if structure.get("fuse_bottleneck") else 0)
-                                            - (1 if structure.get("fuse_stem") else 0))
+            # (round 5: fuse_projection adds layer1's first block - 9 convs in 3 launches instead of 6 in 2; tables of round 4 lack the key)
+            assert len(plan.conv_steps) == ((53 if legacy else 49) - (6 if structure.get("fuse_bottleneck") else 0)
+                                            - (3 if structure.get("fuse_projection") else 0) - (1 if structure.get("fuse_stem") else 0))
             if len(tiles) == len(plan.conv_steps):
                 plan.import_tiles(tiles)
                 assert plan.export_tiles() == [tuple(t) + ((0,) if len(t) == 3 else ()) for t in tiles]
@@ -410,11 +410,11 @@ def test_detector_with_one_launch_bottlenecks(dev, r50):
     xg = x.to(dev)
     try:
         with torch.inference_mode():
-            model.extractor.set_fuse_bottleneck(True)
+            model.extractor.set_fuse_bottleneck(True, projection=True)
             got = [o.cpu() for o in model(xg)]
             model.raise_if_error()
             plan = model.extractor._plan_for(xg)
-            assert len(plan.fused_steps) == 3 and len(plan.conv_steps) == 40 and len(plan.gemm_steps) == 43
+            assert len(plan.fused_steps) == 3 and len(plan.conv_steps) == 40 and len(plan.gemm_steps) == 43      # (projection block included)
             assert [st.name for st in plan.fused_steps] == ["layer1.0.fused", "layer1.1.fused", "layer1.2.fused"]
             assert all(st.desc.amax_in and st.desc.amax_out for st in plan.fused_steps)
             rep = compare_detector_outputs(got, ref)
@@ -422,7 +422,7 @@ def test_detector_with_one_launch_bottlenecks(dev, r50):
             assert rep["ok"] and rep["rows_positional_mismatch"] <= 4 and rep["rows_unmatched"] == 0 and rep["class_mismatch"] == 0, rep
             # what bench.py does: tune() decides the structure by timing one pass with and without; force it on to gate the form
             table = model.tune(xg, precisions=(0, 1, 2), in_flight=2, reps=2, fuse_bottleneck=True, fuse_stem=False)
-            assert table["fuse_bottleneck"] is True and len(table["serial"]) == 40 and len(table["in_flight"]) == 40
+            assert table["fuse_bottleneck"] is True and len(table["serial"]) == len(table["in_flight"]) == (40 if table["fuse_projection"] else 43)
             for depth, sched in ((1, "serial"), (2, "in_flight")):
                 server = InFlightDetector(model, xg, depth=depth, tiles=table)
                 outs = [o.cpu() for o in server.result(server.submit(xg))]
@@ -432,8 +432,8 @@ def test_detector_with_one_launch_bottlenecks(dev, r50):
                 assert r["ok"] and r["rows_positional_mismatch"] <= 4 and r["rows_unmatched"] == 0 and r["class_mismatch"] == 0, r
             auto = model.tune(xg, precisions=(0, 1, 2), schedules=("serial",), reps=2, heads=False)
             print("tune(fuse_bottleneck='auto', fuse_stem='auto') chose", auto["fuse_bottleneck"], auto["fuse_stem"])
-            assert len(auto["serial"]) == (40 if auto["fuse_bottleneck"] else 49) - (1 if auto["fuse_stem"] else 0)
-            assert model.extractor.fuse_bottleneck == auto["fuse_bottleneck"] and model.extractor.fuse_stem == auto["fuse_stem"]
+            assert len(auto["serial"]) == 49 - (6 if auto["fuse_bottleneck"] else 0) - (3 if auto["fuse_projection"] else 0) - (1 if auto["fuse_stem"] else 0)
+            assert model.extractor.fuse_bottleneck == auto["fuse_bottleneck"] and model.extractor.fuse_projection == auto["fuse_projection"] and model.extractor.fuse_stem == auto["fuse_stem"]
     finally:
         model.extractor.set_structure(None)
         model.rpn.__dict__.get("_gemm_choice", {}).clear()
@@ -487,7 +487,7 @@ def test_detector_with_the_one_launch_stem(dev, r50):
                 model.raise_if_error()
             # what bench.py serves: tune() decides by timing; force it on to gate the form
             table = model.tune(xg, precisions=(0, 1, 2), in_flight=2, reps=2, fuse_stem=True)
-            assert table["fuse_stem"] is True and len(table["serial"]) == (39 if table["fuse_bottleneck"] else 48)
+            assert table["fuse_stem"] is True and len(table["serial"]) == 48 - (6 if table["fuse_bottleneck"] else 0) - (3 if table["fuse_projection"] else 0)
             for depth, sched in ((1, "serial"), (2, "in_flight")):
                 server = InFlightDetector(model, xg, depth=depth, tiles=table)
                 outs = [o.cpu() for o in server.result(server.submit(xg))]
@@ -538,8 +538,8 @@ def test_config3_batch16_in_the_form_bench_times(dev):
     xg = x.to(dev)
     with torch.inference_mode():
         table = model.tune(xg, precisions=(0, 1, 2), in_flight=2, reps=2)
-        assert set(table) == {"serial", "in_flight", "heads", "fuse_bottleneck", "fuse_stem"}
-        assert len(table["serial"]) == len(table["in_flight"]) == (40 if table["fuse_bottleneck"] else 49) - (1 if table["fuse_stem"] else 0)
+        assert set(table) == {"serial", "in_flight", "heads", "fuse_bottleneck", "fuse_projection", "fuse_stem"}
+        assert len(table["serial"]) == len(table["in_flight"]) == 49 - (6 if table["fuse_bottleneck"] else 0) - (3 if table["fuse_projection"] else 0) - (1 if table["fuse_stem"] else 0)
         n_h2 = sum(1 for r in table["serial"] if r[3] == 2)
         for sched, depth in (("serial", 1), ("in_flight", 2)):
             server = InFlightDetector(model, xg, depth=depth, tiles=table)

@@ -137,7 +137,7 @@ def test_tuned_table_is_cached_on_disk_and_a_second_start_does_not_tune(dev, tmp
         t_hit = time.perf_counter() - t0
         assert hit.get("cached") is True and t_hit < 2.0 and t_hit < t_tune, (t_hit, t_tune)
         assert [list(r) for r in hit["serial"]] == [list(r) for r in table["serial"]] and hit["heads"] == table["heads"]
-        assert hit["fuse_stem"] == table["fuse_stem"] and hit["fuse_bottleneck"] == table["fuse_bottleneck"]
+        assert all(hit[k] == table[k] for k in ("fuse_stem", "fuse_bottleneck", "fuse_projection"))
         assert m2.extractor._plan_for(x).export_tiles() == m1.extractor._plan_for(x).export_tiles()
         out2 = m2(x)
         for a, b in zip(out1, out2):

@@ -520,7 +520,7 @@ def test_in_flight_replays_survive_host_copies_between_them(dev):
     model, _ = synthetic_detector("resnet50", num_classes=20, seed=0)
     model = model.to(dev).eval()
     model.extractor.set_conv_precision("fp16x2")
-    model.extractor.set_structure({"fuse_stem": True, "fuse_bottleneck": True})
+    model.extractor.set_structure({"fuse_stem": True, "fuse_bottleneck": True, "fuse_projection": True})
     x = _img((1, 3, 480, 640), seed=17).to(dev)
     with torch.inference_mode():
         ref = [o.clone() for o in model(x)]

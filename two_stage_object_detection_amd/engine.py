@@ -930,10 +930,14 @@ class PlanOwner:
                                  # (set False + invalidate_packed() for the one-launch-per-conv plan, e.g. to pin a tile
                                  # table recorded from it)
 
-    def set_fuse_bottleneck(self, on: bool):
-        """Switch the one-launch bottlenecks on / off for plans built from now on (existing plans are dropped, packed weights stay)."""
-        if bool(on) != bool(self.fuse_bottleneck):
-            self.fuse_bottleneck = bool(on)
+    fuse_projection = False      # ... and (with fuse_bottleneck) the block with the 1x1 projection shortcut at stride 1 (layer1.0) too
+
+    def set_fuse_bottleneck(self, on: bool, projection: bool = False):
+        """Switch the one-launch bottlenecks on / off for plans built from now on (existing plans are dropped, packed weights stay).
+        ``projection``: the block whose shortcut is a 1x1 projection (layer1.0) as one launch too (only with ``on``)."""
+        projection = bool(on) and bool(projection)
+        if bool(on) != bool(self.fuse_bottleneck) or projection != bool(self.fuse_projection):
+            self.fuse_bottleneck, self.fuse_projection = bool(on), projection
             self.__dict__["_plans"] = OrderedDict()
         return self
 
@@ -945,9 +949,9 @@ class PlanOwner:
         return self
 
     def set_structure(self, table) -> "PlanOwner":
-        """The launch structure a tuning table was made for (``FasterRCNN.tune``: "fuse_bottleneck", "fuse_stem"; absent = off)."""
+        """The launch structure a tuning table was made for (``FasterRCNN.tune``: "fuse_bottleneck", "fuse_projection", "fuse_stem"; absent = off)."""
         table = table or {}
-        self.set_fuse_bottleneck(bool(table.get("fuse_bottleneck", False)))
+        self.set_fuse_bottleneck(bool(table.get("fuse_bottleneck", False)), bool(table.get("fuse_projection", False)))   # (tables of round 4: identity blocks only)
         self.set_fuse_stem(bool(table.get("fuse_stem", False)))
         return self
 

@@ -39,7 +39,7 @@ class _ResidualBlock(nn.Module):
         # them, whose shortcut is a 1x1 projection at stride 1 (layer1.0): conv3 + shortcut as one stacked-K GEMM inside the launch
         if getattr(plan, "fuse_bottleneck", False) and len(self._stage_names) == 3:
             ident = self.downsample is None and self.conv1.in_channels == self.conv3.out_channels
-            proj = (self.downsample is not None and len(self.downsample) == 2 and isinstance(self.downsample[0], nn.Conv2d)
+            proj = (getattr(plan, "fuse_projection", False) and self.downsample is not None and len(self.downsample) == 2 and isinstance(self.downsample[0], nn.Conv2d)
                     and self.downsample[0].kernel_size == (1, 1) and self.downsample[0].stride == (1, 1) and self.downsample[0].groups == 1)
             if ((ident or proj) and self.conv1.out_channels == 64 and self.conv2.groups == 1 and self.conv2.stride == (1, 1)
                     and self.conv1.in_channels % 64 == 0 and self.conv3.out_channels % 64 == 0):
@@ -182,6 +182,7 @@ class ResNet(PlanOwner, nn.Module):
         plan.precision = {"f32": 0, "bf16x3": 1, "fp16x2": 2}[self.conv_precision]
         plan.fuse_shortcut = bool(self.fuse_shortcut)
         plan.fuse_bottleneck = bool(self.fuse_bottleneck)
+        plan.fuse_projection = bool(self.fuse_projection)
         x4 = plan.pool.alloc((N, H, W, 4))
         plan.input_nhwc = x4
         oh, ow = (H - 1) // 2 + 1, (W - 1) // 2 + 1

@@ -140,7 +140,7 @@ class FasterRCNN(nn.Module):
         ONE launch that reads the images where they are, NCHW or NHWC4 (tsod_stem_fp16x2: no layout pass, no 64-channel conv output
         in memory) - "auto" times the input step + the backbone's launches with and without.
         Returns the tables as plain JSON-able data {"serial": [...], "in_flight": [...], "heads": {...}, "fuse_bottleneck": bool,
-        "fuse_stem": bool}
+        "fuse_projection": bool (round 5: layer1's first block, whose shortcut is a 1x1 projection, as one launch too), "fuse_stem": bool}
         - feed it back through ``import_tuning`` (another process, another rank) or ``InFlightDetector(tiles=...)``.  Afterwards
         the plan of slot 0 runs the serial table when that was tuned, else the in-flight one.
         ``cache_dir``: keep the table on disk (weight_cache.save_tuning), keyed by the weights + config hash, the device name, the
@@ -213,30 +213,34 @@ class FasterRCNN(nn.Module):
             self(example)                                           # builds the plan; leaves real activations (and range words) behind
             plan = ext._plan_for(example)
             table[want[0]] = tune_schedule(plan, want[0])
-            fused = False
+            fused, fused_proj = False, False
             if can_fuse and fuse_bottleneck and 2 in tuple(precisions):
+                # three structures of layer1, one pass over the matrix launches each: three launches per block; the identity blocks as
+                # ONE launch each; the block with the projection shortcut too.  A tie within 3 % goes to fewer launches: what they save -
+                # the intermediates' bytes, the launches - counts for more with several forwards in flight than the serial pass shows
+                # (one box, batch 1, serial pass 1340 against 1346 us: 1187 against 1127 images/s with four in flight)
                 t_plain = plan.sequence_time()
-                ext.set_fuse_bottleneck(True)
-                self(example)
-                plan_f = ext._plan_for(example)
-                if plan_f.fused_steps:
-                    plan_f.import_tiles_by_name(table[want[0]])
-                    t_fused = plan_f.sequence_time()
-                    # (a tie goes to the fused structure: what it saves - the intermediates' bytes, four launches - counts for more
-                    #  with several forwards in flight than the serial pass shows; one box, batch 1, serial pass 1340 against 1346 us:
-                    #  1187 against 1127 images/s with four in flight, serial step 1.475 against 1.508 ms)
-                    fused = fuse_bottleneck is True or t_fused < 1.03 * t_plain
-                    if verbose:
-                        print(f"  one-launch bottlenecks ({len(plan_f.fused_steps)}): {t_fused * 1e3:.1f} us per pass against {t_plain * 1e3:.1f} us -> "
-                              f"{'fused' if fused else 'three launches each'}")
-                if fused:
-                    plan = plan_f
-                    table[want[0]] = plan.export_tiles()
-                else:
-                    ext.set_fuse_bottleneck(False)
+                tried = {}
+                for proj in (False, True):
+                    ext.set_fuse_bottleneck(True, projection=proj)
                     self(example)
-                    plan = ext._plan_for(example)
-                    plan.import_tiles(table[want[0]])
+                    plan_f = ext._plan_for(example)
+                    n_f = len([st for st in plan_f.fused_steps if st is not plan_f.stem_step])
+                    if n_f and n_f not in [v[1] for v in tried.values()]:
+                        plan_f.import_tiles_by_name(table[want[0]])
+                        tried[proj] = (plan_f.sequence_time(), n_f)
+                        if verbose:
+                            print(f"  one-launch bottlenecks ({n_f}): {tried[proj][0] * 1e3:.1f} us per pass against {t_plain * 1e3:.1f} us for three launches each")
+                cands = [] if fuse_bottleneck is True else [(t_plain, 0, False, False)]
+                cands += [(t_f, n_f, True, proj) for proj, (t_f, n_f) in tried.items()]
+                if cands:                                           # within 3 % of the fastest structure: the one with the most one-launch blocks
+                    t_min = min(c[0] for c in cands)
+                    _, _, fused, fused_proj = max((c for c in cands if c[0] <= 1.03 * t_min), key=lambda c: (c[1], -c[0]))
+                ext.set_fuse_bottleneck(fused, projection=fused_proj)
+                self(example)
+                plan = ext._plan_for(example)
+                plan.import_tiles_by_name(table[want[0]])
+                table[want[0]] = plan.export_tiles()
             if can_stem:
                 # the stem's structure: the tuned three launches (layout pass, conv1, max pool) against the one launch
                 stem = self._stem_pays(example, plan, verbose) or fuse_stem is True
@@ -249,6 +253,7 @@ class FasterRCNN(nn.Module):
                 table[sched] = tune_schedule(plan, sched)
             plan.import_tiles(table.get("serial") or table["in_flight"])
             table["fuse_bottleneck"] = bool(fused)
+            table["fuse_projection"] = bool(fused_proj)
             table["fuse_stem"] = bool(stem)
             if heads:
                 self.autotune_heads(example)
