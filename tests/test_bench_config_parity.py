@@ -61,6 +61,8 @@ def test_detector_with_the_committed_autotuned_tile_tables(dev, r50, table):
     tiles = blob if key is None else blob[key]
     # (the comparison legs' tables "f32" / "bf16x3" are always recorded on the plain structure)
     structure = {k: bool(blob.get(k, False)) for k in ("fuse_bottleneck", "fuse_projection", "fuse_stem")} if key in ("serial", "in_flight") else {}
+    if structure.get("fuse_bottleneck") and "fuse_projection" not in blob:        # (a table without the key: what its rows say)
+        structure["fuse_projection"] = not any(r[0] == "layer1.0.conv1" for r in tiles)
     xg = x.to(dev)
     legacy = any(r[0].endswith(".downsample") for r in tiles)       # tables recorded before the shortcut fusion: 53 convs
     with torch.inference_mode():
