@@ -553,6 +553,19 @@ class Plan:
         self.clear_range_flag()      # (these launches ran on whatever the pooled buffers held, not on a forward's activations)
         return e0.elapsed_time(e1) / reps
 
+    def forward_time(self, reps: int = 5) -> float:
+        """HIP-event time (ms) of ONE pass over EVERY launch of the plan (``launch()``: range-word reset, layout pass, max pool and
+        depthwise launches included) on the input bound last, averaged over ``reps`` passes issued back to back: real activations
+        at every layer, which a pass over the matrix launches alone does not have.  What FasterRCNN.tune compares structures by."""
+        self.launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            self.launch()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
     def capture(self):
         """Record the plan into a HIP graph (one graph launch per forward afterwards)."""
         torch.cuda.synchronize(self.device)
