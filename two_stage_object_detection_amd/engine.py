@@ -1003,7 +1003,8 @@ class PlanOwner:
         device = torch.device(device)
         if device not in mirrors:
             from ctypes import c_void_p
-            host = torch.zeros(self.RANGE_WORDS, dtype=torch.int32).pin_memory()
+            with torch.inference_mode(False):                      # (written from outside inference mode too: raise_if_error)
+                host = torch.zeros(self.RANGE_WORDS, dtype=torch.int32).pin_memory()
             dptr = c_void_p(0)
             with torch.cuda.device(device):
                 rc = lib().tsod_host_mapped_pointer(host.data_ptr(), byref(dptr))

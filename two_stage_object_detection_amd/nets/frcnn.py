@@ -320,7 +320,9 @@ class FasterRCNN(nn.Module):
         d0 = d = figure()
         demoted = []
         if d > budget:
-            cands = [i for i, r in enumerate(rows) if int(r[3]) != 0] + ([-1] if int(tuned_rpn[2]) != 0 else [])
+            # (a layer tuned to the f32 kernel under another tile or K split sums in another order than the reference plan: it is a
+            # candidate too, so that a budget of zero ends at the reference plan itself)
+            cands = [i for i, r in enumerate(rows) if tuple(int(v) for v in r[1:4]) != (0, 0, 0)] + ([-1] if tuple(tuned_rpn) != (0, 0, 0) else [])
             price = []
             for i in cands:                                         # the figure with layer i alone on the f32 kernel
                 keep = rpn_now if i < 0 else rows[i]
