@@ -24,8 +24,10 @@ L.tsod_debug_set_dma_stamps.argtypes = [ctypes.c_void_p]
 buf = torch.zeros(8 * 8192, dtype=torch.int64, device=dev)
 SHAPES = [(50, 84, 256, 256, 3, "layer3.conv2"), (25, 42, 512, 512, 3, "layer4.conv2"), (100, 167, 128, 128, 3, "layer2.conv2"),
           (50, 84, 1024, 256, 1, "layer3.conv1"), (50, 84, 256, 1024, 1, "layer3.conv3"), (25, 42, 2048, 512, 1, "layer4.conv1"),
-          (200, 334, 64, 64, 3, "layer1.conv2")]
-SCHEDS = [(17, 1), (18, 1), (18, 3), (20, 1), (22, 1), (22, 3), (22, -1), (22, -2), (19, -1), (24, 1), (24, -1), (24, 2), (24, -2)]
+          (200, 334, 64, 64, 3, "layer1.conv2"), (100, 167, 128, 512, 1, "layer2.conv3"), (100, 167, 512, 128, 1, "layer2.conv1"),
+          (25, 42, 512, 2048, 1, "layer4.conv3")]
+# (register-staged tiles carry no stamps: their rows show the launch time only)
+SCHEDS = [(8, 1), (8, -1), (10, 1), (14, 1), (15, 1), (15, -1), (16, 1), (17, 1), (18, 1), (18, 3), (20, 1), (22, 1), (22, 3), (22, -1), (22, -2), (19, -1), (24, 1), (24, -1), (24, 2), (24, -2)]
 PREC = int(os.environ.get("TSOD_TIMELINE_PREC", "1"))          # 1 = bf16x3, 2 = fp16x2 (tile d128x128k32 only)
 if len(sys.argv) > 2:
     SHAPES = [s for s in SHAPES if s[5] in sys.argv[2].split(",")]
@@ -63,6 +65,9 @@ for (H, W, Cin, Cout, k, name) in SHAPES:
         s = buf.view(-1, 8).cpu().double()
         s = s[s[:, 1] > 0]
         n = s.shape[0]
+        if n == 0:
+            print(f"  {TILE_NAMES[tile]:9s} split {split:2d}: {us:6.1f} us/launch {fl / us / 1e6:6.1f} TF/s | (register-staged: no stamps)", flush=True)
+            continue
         t0 = s[:, 0].min()
         start, end = (s[:, 0] - t0) / 100.0, (s[:, 1] - t0) / 100.0                  # us (100 MHz)
         life = end - start
