@@ -250,13 +250,14 @@ def proposal_layer(loc, score, anchor, img_size, scale=1.0, mode="training", ret
     roi_s, score_s = roi_v[order], score_v[order]
     keep = nms(roi_s, score_s, _PROPOSAL_CFG["nms_iou"])
     n_kept = int(keep.numel())
+    keep_all = keep                  # (every survivor in score order: what lies just beyond the n_post cut, for the checker's tie rule)
     if n_kept < n_post:
         keep = torch.cat([keep, torch.arange(n_post - n_kept, dtype=keep.dtype)])
     keep = keep[:n_post]
     out = roi_s[keep]            # IndexError here if the pad runs past the candidates (Q4)
     if return_debug:
         return out, {"decoded": roi, "valid": ok, "sorted_src": valid_idx[order], "roi_sorted": roi_s,
-                     "score_sorted": score_s, "keep": keep, "n_kept": n_kept}
+                     "score_sorted": score_s, "keep": keep, "n_kept": n_kept, "keep_all": keep_all}
     return out
 
 

@@ -325,6 +325,65 @@ def test_compare_detector_outputs_is_one_to_one():
     assert not rep["ok"] and rep["rows_unmatched"] == 1
 
 
+def test_a_score_tie_at_the_cut_of_the_proposal_list_is_a_tie_not_a_missing_row():
+    """compare_detector_outputs(ref_cutoff=): the proposal layer keeps the R best NMS survivors; when the R-th and the (R+1)-th
+    differ by a couple of ulps of their fg probability either pipeline may put either in the last place (config 4 on bench.py's
+    input: 0.99836999 against 0.99836987).  With the reference's own record of what it cut off (testing.cutoff_candidates of the
+    oracle's RPN debug) such a row is a tie - counted, reported with its score gap - and nothing else is: the same displaced row
+    with a REAL score gap, or a row that is no candidate of the reference at all, stays unmatched."""
+    from oracle.box import proposal_layer
+    from two_stage_object_detection_amd.testing import compare_detector_outputs, cutoff_candidates
+    g = torch.Generator().manual_seed(5)
+    R, n = 12, 5
+    rois = torch.rand(1, R, 4, generator=g) * 500
+    scores = torch.randn(1, R, n, generator=g)
+    locs = torch.randn(1, R, 4 * n, generator=g)
+    idx = torch.zeros(1, dtype=torch.int32)
+    ref = (locs, scores, rois, idx)
+    nxt = torch.tensor([[10., 20., 90., 140.], [300., 310., 420., 470.]])          # the two candidates the reference cut off
+    kept_sc = torch.linspace(0.9999, 0.9984, R)
+    cut = [(nxt, torch.tensor([float(kept_sc[-1]) - 1.2e-7, 0.9950]), kept_sc)]
+    got_rois = rois.clone()
+    got_rois[0, R - 1] = nxt[0] + 3e-4                                              # the other pipeline kept candidate R + 1 instead
+    got = (locs, scores, got_rois, idx)
+    plain = compare_detector_outputs(got, ref)
+    assert not plain["ok"] and plain["rows_unmatched"] == 1
+    rep = compare_detector_outputs(got, ref, ref_cutoff=cut)
+    assert rep["ok"] and rep["rows_unmatched"] == 0 and rep["rows_tied_at_cutoff"] == 1 and 1.0e-7 < rep["max_tie_score_gap"] < 1.5e-7
+    # the same swap with a score gap that is no tie
+    far = [(nxt, torch.tensor([float(kept_sc[-1]) - 1e-4, 0.9950]), kept_sc)]
+    rep = compare_detector_outputs(got, ref, ref_cutoff=far)
+    assert not rep["ok"] and rep["rows_unmatched"] == 1 and rep["rows_tied_at_cutoff"] == 0
+    # a row that is none of the reference's candidates
+    other = rois.clone()
+    other[0, R - 1] = torch.tensor([1., 2., 3., 4.])
+    rep = compare_detector_outputs((locs, scores, other, idx), ref, ref_cutoff=cut)
+    assert not rep["ok"] and rep["rows_unmatched"] == 1 and rep["rows_tied_at_cutoff"] == 0
+    # a displaced row in the MIDDLE of the list whose score is nowhere near the cut: not a tie either
+    mid = rois.clone()
+    mid[0, 2] = nxt[0]
+    mid_cut = [(nxt, torch.tensor([float(kept_sc[-1]) - 1.2e-7, 0.9950]), kept_sc)]
+    rep = compare_detector_outputs((locs, scores, mid, idx), ref, ref_cutoff=mid_cut)
+    assert not rep["ok"] and rep["rows_unmatched"] == 1
+    # cutoff_candidates reads the oracle's debug record: the survivors past n_post in score order, None for a padded list
+    A = 400
+    gg = torch.Generator().manual_seed(9)
+    anchor = torch.rand(A, 2, generator=gg) * 600
+    anchor = torch.cat([anchor, anchor + 40 + torch.rand(A, 2, generator=gg) * 100], dim=1)
+    loc = torch.zeros(A, 4)
+    sc = torch.rand(A, generator=gg)
+    out, dbg = proposal_layer(loc, sc, anchor, (3, 800, 800), return_debug=True)
+    n_post = out.shape[0]
+    c = cutoff_candidates({"per_image": [dbg]}, n_post)[0]
+    if dbg["n_kept"] > n_post:
+        ext, ext_sc, k_sc = c
+        assert torch.equal(k_sc, dbg["score_sorted"][dbg["keep_all"][:n_post]]) and float(ext_sc[0]) <= float(k_sc[-1])
+        assert torch.equal(ext[0], dbg["roi_sorted"][dbg["keep_all"][n_post]])
+    else:
+        assert c is None
+    assert cutoff_candidates({"per_image": [dbg]}, 10)[0] is not None and cutoff_candidates({"per_image": [dbg]}, 10 ** 6)[0] is None
+
+
 def test_bottleneck_weight_stream_layout():
     """hip_ops.pack_bottleneck_wstream against the layout include/tsod.h documents (what bottleneck_kernel's lanes load): 8 KB
     steps in consumption order (conv1's K-steps, conv2's (tap, channel half) steps, conv3's 64-channel slices x 2 K-steps); a

@@ -1067,7 +1067,11 @@ class PlanOwner:
         self.__dict__["_packed_cache"] = {}
         self.__dict__.setdefault("_a_exps", {}).clear()
         self.__dict__["_range_words"] = {}       # (per device; the plans that pointed at the old words are gone with them)
-        self.__dict__["_range_mirrors"] = {}
+        # the host mirrors STAY: a graph somebody still holds has the mirror's mapped address baked into its last launch, and page-
+        # locked memory handed back to the allocator could be anybody's by the time that graph is replayed
+        for m in self.__dict__.get("_range_mirrors", {}).values():
+            if m is not None:
+                m[0].zero_()
         self.__dict__["weights_version"] = self.__dict__.get("weights_version", 0) + 1
 
     def _bump_version(self):
