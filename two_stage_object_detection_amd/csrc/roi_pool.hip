@@ -120,41 +120,24 @@ roi_pool_avg_kernel(const float *__restrict__ feat, int B, int Hf, int Wf, int C
             // Neighbouring bins of a row share at most ONE pixel column (floor / ceil edges of a float bin width): its column maximum is
             // kept from the bin before instead of being read again - a window pixel is read once per bin ROW it belongs to, not once
             // per bin (a 7-bin row read 1.2-2x its width before).  A maximum taken in another order is the same maximum: bit-exact.
-            // The columns a bin adds are read two at a time, four rows each, ALL EIGHT loads issued before the first maximum (rows and
-            // the second column clamped into the window: a pixel taken twice does not change a maximum) - one L2 round trip per
-            // eight pixels instead of one per pixel, which was the kernel's time (a thread's chain was ~25 dependent-in-order loads).
             int kept_x = -1;
             float4 kept = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
-            const long rs = (long)Wf * pitch;
             for (int pw = 0; pw < PW; ++pw) {
                 int ws, we;
                 bin_range(pw, bin_w, g.sw, Wf, ws, we);
                 float4 m = make_float4(0.f, 0.f, 0.f, 0.f);                   // empty bin
                 if (he > hs && we > ws) {
                     m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
-                    int w = ws;
-                    if (ws == kept_x) { m = kept; ++w; }
-                    float4 last = kept;
-                    for (; w < we; w += 2) {
-                        const int w2 = min(w + 1, we - 1);
-                        const float *p0 = fmap + ((long)hs * Wf + w) * pitch + 4 * c4;
-                        const float *p1 = p0 + (long)(w2 - w) * pitch;
-                        float4 c0 = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX), c1 = c0;
-                        for (int h = hs; h < he; h += 4) {
-                            const long o0 = (long)(h - hs) * rs, o1 = (long)(min(h + 1, he - 1) - hs) * rs,
-                                       o2 = (long)(min(h + 2, he - 1) - hs) * rs, o3 = (long)(min(h + 3, he - 1) - hs) * rs;
-                            const float4 a0 = *reinterpret_cast<const float4 *>(p0 + o0), a1 = *reinterpret_cast<const float4 *>(p0 + o1),
-                                         a2 = *reinterpret_cast<const float4 *>(p0 + o2), a3 = *reinterpret_cast<const float4 *>(p0 + o3),
-                                         b0 = *reinterpret_cast<const float4 *>(p1 + o0), b1 = *reinterpret_cast<const float4 *>(p1 + o1),
-                                         b2 = *reinterpret_cast<const float4 *>(p1 + o2), b3 = *reinterpret_cast<const float4 *>(p1 + o3);
-                            c0 = max4(c0, max4(max4(a0, a1), max4(a2, a3)));
-                            c1 = max4(c1, max4(max4(b0, b1), max4(b2, b3)));
+                    for (int w = ws; w < we; ++w) {
+                        float4 col = kept;
+                        if (w != kept_x) {
+                            col = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+                            const float *colp = fmap + ((long)hs * Wf + w) * pitch + 4 * c4;
+                            for (int h = hs; h < he; ++h, colp += (long)Wf * pitch) col = max4(col, *reinterpret_cast<const float4 *>(colp));
                         }
-                        m = max4(m, max4(c0, c1));
-                        last = c1;                                            // (the loop ends on column we - 1)
+                        m = max4(m, col);
+                        if (w == we - 1) { kept = col; kept_x = w; }
                     }
-                    kept = last;
-                    kept_x = we - 1;
                 }
                 acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
             }
