@@ -833,28 +833,26 @@ class Plan:
         return out
 
 
-def refine_in_flight(plans, shortlist, rounds: int = 4, verbose: bool = False):
-    """Second look at a tile table whose objective is SEVERAL requests in flight (serving.InFlightDetector): ``plans`` are the
-    backbone plans of the server's slots (same geometry, own buffers and workspaces), ``shortlist[i]`` the candidates of conv
-    layer i (``Plan.autotune(..., keep_shortlist=k)``: its k fastest by the first look, which times copies of ONE layer side by
-    side on hot operands).  Here every slot's stream runs the whole conv sequence, the slots STAGGERED around it (slot s starts
-    s / n of the way in, wrapping), so that at any moment the chip holds launches of different layers, as a pipelined server
-    does; the time of ``rounds`` such passes is the figure of merit.  One sweep over the layers: the candidate that makes the
-    passes fastest is pinned in every plan.  Stale activations are read where the rotation puts a consumer ahead of its
-    producer - timing only; the plans are finalized (workspaces re-bound) on return.  Returns the table (export_tiles)."""
-    import statistics
-    n = len(plans)
-    dev = plans[0].device
-    L = len(plans[0].conv_steps)
-    streams = [torch.cuda.Stream(dev) for _ in range(n)]
-    offs = [(s * L) // n for s in range(n)]
-    cur = torch.cuda.current_stream(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    bigs = [torch.zeros(512 << 20, dtype=torch.uint8, device=dev) for _ in range(n)]        # zero tickets, any candidate's slabs
+class InFlightMeter:
+    """The figure of merit of a tile table under SEVERAL requests in flight: every slot's stream runs the whole conv sequence of its
+    plan, the slots staggered around it (slot s starts s / n of the way in, wrapping), ``rounds`` passes; ``measure`` = the median
+    of three such timings (ms).  Stale activations are read where the rotation puts a consumer ahead of its producer - timing only."""
 
-    def all_args():
+    def __init__(self, plans, rounds: int = 4):
+        self.plans, self.rounds = plans, rounds
+        self.n = len(plans)
+        dev = plans[0].device
+        self.L = len(plans[0].conv_steps)
+        self.streams = [torch.cuda.Stream(dev) for _ in range(self.n)]
+        self.offs = [(s * self.L) // self.n for s in range(self.n)]
+        self.cur = torch.cuda.current_stream(dev)
+        self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.bigs = [torch.zeros(512 << 20, dtype=torch.uint8, device=dev) for _ in range(self.n)]   # zero tickets, any candidate's slabs
+
+    def args(self):
+        """the launches of every plan as they stand now (call again after a choose()), on the meter's own workspaces"""
         out = []
-        for pl, big in zip(plans, bigs):
+        for pl, big in zip(self.plans, self.bigs):
             rows = []
             for st in pl.conv_steps:
                 a = list(st.args)
@@ -863,7 +861,10 @@ def refine_in_flight(plans, shortlist, rounds: int = 4, verbose: bool = False):
             out.append(rows)
         return out
 
-    def measure(args):
+    def measure(self, args=None):
+        import statistics
+        args = self.args() if args is None else args
+        streams, cur, e0, e1, L = self.streams, self.cur, self.e0, self.e1, self.L
         ts = []
         for _ in range(3):
             for st_ in streams:
@@ -872,10 +873,10 @@ def refine_in_flight(plans, shortlist, rounds: int = 4, verbose: bool = False):
             for st_ in streams:
                 st_.wait_event(e0)
             rc = 0
-            for _r in range(rounds):
+            for _r in range(self.rounds):
                 for j in range(L):
                     for s_, st_ in enumerate(streams):
-                        fn, a = args[s_][(j + offs[s_]) % L]
+                        fn, a = args[s_][(j + self.offs[s_]) % L]
                         rc |= fn(*a, st_.cuda_stream)
             for st_ in streams:
                 cur.wait_stream(st_)
@@ -885,6 +886,41 @@ def refine_in_flight(plans, shortlist, rounds: int = 4, verbose: bool = False):
                 return None
             ts.append(e0.elapsed_time(e1))
         return statistics.median(ts)
+
+
+def best_table_in_flight(plans, tables: dict, rounds: int = 4, turns: int = 3):
+    """Which of several whole tile tables (name -> export_tiles rows of the plans' structure) serves ``len(plans)`` requests in
+    flight fastest: each is pinned in every plan and timed with the staggered-streams measure (InFlightMeter), the tables in turn,
+    the best of ``turns`` turns each.  The fastest stays pinned.  Returns (its name, {name: us of conv time per forward})."""
+    meter = InFlightMeter(plans, rounds)
+    best = {k: float("inf") for k in tables}
+    for _ in range(turns):
+        for k, rows in tables.items():
+            for pl in plans:
+                pl.import_tiles(rows)
+            t = meter.measure()
+            if t is not None:
+                best[k] = min(best[k], t)
+    name = min(best, key=best.get)
+    del meter
+    for pl in plans:
+        pl.import_tiles(tables[name])
+        pl.clear_range_flag()
+    return name, {k: v / rounds / len(plans) * 1e3 for k, v in best.items()}
+
+
+def refine_in_flight(plans, shortlist, rounds: int = 4, verbose: bool = False):
+    """Second look at a tile table whose objective is SEVERAL requests in flight (serving.InFlightDetector): ``plans`` are the
+    backbone plans of the server's slots (same geometry, own buffers and workspaces), ``shortlist[i]`` the candidates of conv
+    layer i (``Plan.autotune(..., keep_shortlist=k)``: its k fastest by the first look, which times copies of ONE layer side by
+    side on hot operands).  Here every slot's stream runs the whole conv sequence, the slots STAGGERED around it (slot s starts
+    s / n of the way in, wrapping), so that at any moment the chip holds launches of different layers, as a pipelined server
+    does; the time of ``rounds`` such passes is the figure of merit.  One sweep over the layers: the candidate that makes the
+    passes fastest is pinned in every plan.  Stale activations are read where the rotation puts a consumer ahead of its
+    producer - timing only; the plans are finalized (workspaces re-bound) on return.  Returns the table (export_tiles)."""
+    meter = InFlightMeter(plans, rounds)
+    n, L = meter.n, meter.L
+    all_args, measure = meter.args, meter.measure
 
     base = measure(all_args())
     changed = 0
@@ -907,7 +943,7 @@ def refine_in_flight(plans, shortlist, rounds: int = 4, verbose: bool = False):
                 print(f"  in flight: {plans[0].conv_steps[i].name:34s} {TILE_NAMES[keep[0]]} split {keep[1]} -> {TILE_NAMES[best_c[0]]} split {best_c[1]}"
                       f"   ({base / rounds / n * 1e3:.1f} -> {best_t / rounds / n * 1e3:.1f} us of conv time per forward)")
         base = best_t
-    del bigs
+    del meter
     for pl in plans:
         pl.finalize()
     if verbose:
