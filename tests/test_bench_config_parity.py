@@ -489,6 +489,12 @@ def test_detector_with_the_one_launch_stem(dev, r50):
                 model.raise_if_error()
             # what bench.py serves: tune() decides by timing; force it on to gate the form
             table = model.tune(xg, precisions=(0, 1, 2), in_flight=2, reps=2, fuse_stem=True)
+            chk = table.get("in_flight_check")               # (batch 1: the in-flight table is refined, then held against the serial one)
+            if table["serial"] != table["in_flight"] or chk is not None:
+                assert chk is not None and chk["kept"] in ("in_flight", "serial") and set(chk["conv_us_per_forward"]) == {"in_flight", "serial"}
+                assert all(v > 0 for v in chk["conv_us_per_forward"].values())
+                if chk["kept"] == "serial":
+                    assert table["in_flight"] == table["serial"]
             assert table["fuse_stem"] is True and len(table["serial"]) == 48 - (6 if table["fuse_bottleneck"] else 0) - (3 if table["fuse_projection"] else 0)
             for depth, sched in ((1, "serial"), (2, "in_flight")):
                 server = InFlightDetector(model, xg, depth=depth, tiles=table)
@@ -540,7 +546,7 @@ def test_config3_batch16_in_the_form_bench_times(dev):
     xg = x.to(dev)
     with torch.inference_mode():
         table = model.tune(xg, precisions=(0, 1, 2), in_flight=2, reps=2)
-        assert set(table) == {"serial", "in_flight", "heads", "fuse_bottleneck", "fuse_projection", "fuse_stem"}
+        assert set(table) - {"in_flight_check"} == {"serial", "in_flight", "heads", "fuse_bottleneck", "fuse_projection", "fuse_stem"}
         assert len(table["serial"]) == len(table["in_flight"]) == 49 - (6 if table["fuse_bottleneck"] else 0) - (3 if table["fuse_projection"] else 0) - (1 if table["fuse_stem"] else 0)
         n_h2 = sum(1 for r in table["serial"] if r[3] == 2)
         for sched, depth in (("serial", 1), ("in_flight", 2)):
